@@ -1,0 +1,81 @@
+"""
+Operator protocol of the hot path: ``Filter`` / ``ComposedFilter`` /
+``ComposedFilterResults``.
+
+Same class names, constructor shapes and ``apply(ndarray) -> ndarray``
+contract as the reference (`cguerrero/hydrodem/filters/__init__.py:10-127`),
+so orchestration code written against the reference keeps working when
+``filters`` resolves to this package (see ``hydrodem_amd/dropin``).
+
+One addition: every GPU-backed filter also implements
+``apply_device(raster)`` on a :class:`hydrodem_amd.backend.DeviceRaster`, and
+the two composed classes chain through it when every member supports it, so a
+chain pays one host->device and one device->host copy instead of one pair
+per member.
+"""
+
+from abc import ABC, abstractmethod
+
+from numpy import ndarray
+
+from ..exceptions import NumpyArrayExpectedError
+
+
+class Filter(ABC):  # pylint: disable=too-few-public-methods
+    """Base operator.  Subclasses call ``super().apply(x)`` for the type
+    check (filters/__init__.py:23-39)."""
+
+    @abstractmethod
+    def apply(self, image_to_filter):
+        if not isinstance(image_to_filter, ndarray):
+            raise NumpyArrayExpectedError(image_to_filter)
+
+
+def _device_chain(filters):
+    """True when every member can run device-resident."""
+    return bool(filters) and all(
+        callable(getattr(f, "apply_device", None)) for f in filters)
+
+
+class ComposedFilter(Filter):  # pylint: disable=too-few-public-methods
+    """Left-to-right chain over ``self.filters``
+    (filters/__init__.py:42-80)."""
+
+    def __init__(self):
+        self.filters = []
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        if _device_chain(self.filters):
+            from ..backend import DeviceRaster
+            with DeviceRaster.from_host(image_to_filter) as raster:
+                return self.apply_device(raster).to_host()
+        content = image_to_filter
+        for filter_ in self.filters:
+            content = filter_.apply(content)
+        return content
+
+    def apply_device(self, raster):
+        """Chain on a device-resident raster (consumes ``raster``)."""
+        content = raster
+        for filter_ in self.filters:
+            content = filter_.apply_device(content)
+        return content
+
+
+class ComposedFilterResults(Filter):  # pylint: disable=too-few-public-methods
+    """Chain that also keeps every stage in ``results[ClassName]``
+    (filters/__init__.py:83-127); callers read stages by class name
+    (custom_filters.py:658-660,876)."""
+
+    def __init__(self):
+        self.filters = []
+        self.results = dict()
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        content = image_to_filter
+        for filter_ in self.filters:
+            content = filter_.apply(content)
+            self.results[filter_.__class__.__name__] = content
+        return content
