@@ -1,0 +1,426 @@
+"""
+ctypes binding of ``libhydrodem_hip.so`` (C ABI: ``include/hydrodem_hip.h``).
+
+This is the whole host side of the boundary: load the library, map status
+codes to the reference's exception classes, and move NumPy arrays across.
+There is deliberately no CPU implementation behind it -- when the library or
+a GPU is missing every operator raises :class:`BackendError`.
+"""
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from .exceptions import (BackendError, HydroDEMException, NotConvergedError,
+                         WindowSizeEvenError, WindowSizeHighError)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhydrodem_hip.so")
+
+# status codes (include/hydrodem_hip.h)
+OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = range(8)
+
+# kernel ids for the timing query
+K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN = range(7)
+
+FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("launches", ctypes.c_int64), ("ms", ctypes.c_double),
+                ("units", ctypes.c_int64)]
+
+
+class FillStats(ctypes.Structure):
+    _fields_ = [("rounds", ctypes.c_int32), ("converged", ctypes.c_int32),
+                ("tile_visits", ctypes.c_int64), ("tiles", ctypes.c_int64),
+                ("tile_h", ctypes.c_int32), ("tile_w", ctypes.c_int32),
+                ("scans", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+_c = ctypes
+_vp, _i, _f = _c.c_void_p, _c.c_int, _c.c_float
+# name -> argtypes; every function returns int except the three noted
+SIGNATURES = {
+    "hdem_device_count": [_c.POINTER(_i)],
+    "hdem_init": [_i, _c.POINTER(_vp)],
+    "hdem_shutdown": [_vp],
+    "hdem_set_stream": [_vp, _vp],
+    "hdem_synchronize": [_vp],
+    "hdem_malloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
+    "hdem_free": [_vp, _vp],
+    "hdem_memcpy_h2d": [_vp, _vp, _vp, _c.c_size_t],
+    "hdem_memcpy_d2h": [_vp, _vp, _vp, _c.c_size_t],
+    "hdem_memcpy_d2d": [_vp, _vp, _vp, _c.c_size_t],
+    "hdem_profile_enable": [_vp, _i],
+    "hdem_profile_reset": [_vp],
+    "hdem_profile_get": [_vp, _i, _c.POINTER(KernelStat)],
+    "hdem_d8_f32": [_vp, _vp, _i, _i, _vp],
+    "hdem_d8_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_sinkfill_f32": [_vp, _vp, _i, _i, _f, _i, _vp, _c.POINTER(FillStats)],
+    "hdem_sinkfill_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp,
+                              _c.POINTER(FillStats)],
+    "hdem_boxmean3_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_boxmean3_f64": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_boxmean3_f64_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_convolve_f32": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "hdem_around_f32": [_vp, _vp, _c.c_int64, _vp],
+    "hdem_around_f64": [_vp, _vp, _c.c_int64, _vp],
+    "hdem_quadratic_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_quadratic_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_groves_f32": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "hdem_groves_f32_dev": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+}
+OTHER_SYMBOLS = {"hdem_last_error": _c.c_char_p, "hdem_version": _i}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(path=None):
+    """dlopen the HIP library and declare every prototype.  Needs no GPU."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("HYDRODEM_HIP_LIB", LIB_PATH)
+        if not os.path.exists(p):
+            raise BackendError(
+                f"HIP library not found at {p}: build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(there is no CPU fallback)")
+        try:
+            lib = ctypes.CDLL(p)
+        except OSError as exc:
+            raise BackendError(f"cannot load {p}: {exc}") from exc
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        lib.hdem_last_error.argtypes = []
+        lib.hdem_last_error.restype = ctypes.c_char_p
+        lib.hdem_version.argtypes = []
+        lib.hdem_version.restype = ctypes.c_int
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _raise(lib, rc, window=None, shape=None):
+    msg = (lib.hdem_last_error() or b"").decode("utf-8", "replace")
+    if rc == WINDOW_EVEN:
+        raise WindowSizeEvenError(window)
+    if rc == WINDOW_HIGH:
+        raise WindowSizeHighError(window, shape)
+    if rc == NOT_CONVERGED:
+        raise NotConvergedError(msg)
+    if rc == BAD_ARG:
+        raise ValueError(msg)
+    if rc == OOM:
+        raise MemoryError(msg)
+    raise BackendError(msg or f"hydrodem_hip status {rc}")
+
+
+class Context:
+    """One ``hdem_ctx`` (device, stream, workspace).  Use :func:`context`."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        handle = ctypes.c_void_p()
+        rc = self.lib.hdem_init(int(device), ctypes.byref(handle))
+        if rc != OK:
+            _raise(self.lib, rc)
+        self.handle = handle
+        self.device = int(device)
+
+    def check(self, rc, **kw):
+        if rc != OK:
+            _raise(self.lib, rc, **kw)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hdem_shutdown(self.handle)
+            self.handle = None
+
+    def synchronize(self):
+        self.check(self.lib.hdem_synchronize(self.handle))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.hdem_set_stream(self.handle,
+                                            ctypes.c_void_p(stream_ptr or 0)))
+
+    # -- timing ----------------------------------------------------------
+    def profile(self, on=True):
+        self.check(self.lib.hdem_profile_enable(self.handle, int(bool(on))))
+
+    def profile_reset(self):
+        self.check(self.lib.hdem_profile_reset(self.handle))
+
+    def profile_get(self, kernel_id):
+        st = KernelStat()
+        self.check(self.lib.hdem_profile_get(self.handle, kernel_id,
+                                             ctypes.byref(st)))
+        return {"launches": st.launches, "ms": st.ms, "units": st.units}
+
+
+_contexts = {}
+
+
+def context(device=None):
+    """Per-process context of ``device`` (default: ``HYDRODEM_DEVICE`` or 0)."""
+    if device is None:
+        device = int(os.environ.get("HYDRODEM_DEVICE", "0"))
+    with _lock:
+        ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            _contexts[device] = ctx
+    return ctx
+
+
+def device_count():
+    lib = load_library()
+    n = ctypes.c_int(0)
+    lib.hdem_device_count(ctypes.byref(n))
+    return n.value
+
+
+_DTYPES = {np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.uint8)}
+
+
+class DeviceRaster:
+    """A 2-D raster resident in HBM (owning unless wrapped)."""
+
+    def __init__(self, ctx, ptr, shape, dtype, owner=True, keepalive=None):
+        self.ctx, self.ptr, self.shape = ctx, ptr, tuple(shape)
+        self.dtype = np.dtype(dtype)
+        self._owner = owner
+        self._keepalive = keepalive
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+    @classmethod
+    def empty(cls, shape, dtype, ctx=None):
+        ctx = ctx or context()
+        dtype = np.dtype(dtype)
+        if dtype not in _DTYPES:
+            raise ValueError(f"unsupported raster dtype {dtype}")
+        ptr = ctypes.c_void_p()
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        ctx.check(ctx.lib.hdem_malloc(ctx.handle, nbytes, ctypes.byref(ptr)))
+        return cls(ctx, ptr.value, shape, dtype)
+
+    @classmethod
+    def from_host(cls, array, dtype=None, ctx=None):
+        a = np.ascontiguousarray(array, dtype=dtype or (
+            array.dtype if array.dtype in _DTYPES else np.float32))
+        if a.ndim != 2:
+            raise ValueError(f"expected a 2-D raster, got shape {a.shape}")
+        r = cls.empty(a.shape, a.dtype, ctx)
+        r.ctx.check(r.ctx.lib.hdem_memcpy_h2d(r.ctx.handle, r.ptr,
+                                              a.ctypes.data, a.nbytes))
+        return r
+
+    @classmethod
+    def wrap(cls, ptr, shape, dtype, ctx=None, keepalive=None):
+        """Non-owning view of device memory someone else allocated (e.g. a
+        torch tensor: ``wrap(t.data_ptr(), t.shape, np.float32, keepalive=t)``)."""
+        return cls(ctx or context(), int(ptr), shape, dtype, owner=False,
+                   keepalive=keepalive)
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx.check(self.ctx.lib.hdem_memcpy_d2h(self.ctx.handle,
+                                                    out.ctypes.data, self.ptr,
+                                                    out.nbytes))
+        return out
+
+    def free(self):
+        if self._owner and self.ptr:
+            self.ctx.lib.hdem_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+# ---------------------------------------------------------------------------
+# device-resident operators (thin: one C call each)
+# ---------------------------------------------------------------------------
+
+def _need(r, dtype):
+    if r.dtype != np.dtype(dtype):
+        raise ValueError(f"expected a {np.dtype(dtype)} raster, got {r.dtype}")
+
+
+def d8_dev(z, out=None):
+    _need(z, np.float32)
+    out = out or DeviceRaster.empty(z.shape, np.uint8, z.ctx)
+    c = z.ctx
+    c.check(c.lib.hdem_d8_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], out.ptr))
+    return out
+
+
+def sinkfill_dev(z, eps=0.0, max_rounds=0, out=None, flags=FILL_INIT):
+    _need(z, np.float32)
+    out = out or DeviceRaster.empty(z.shape, np.float32, z.ctx)
+    c = z.ctx
+    st = FillStats()
+    c.check(c.lib.hdem_sinkfill_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1],
+                                        float(eps), int(max_rounds), int(flags),
+                                        out.ptr, ctypes.byref(st)))
+    return out, st.as_dict()
+
+
+def boxmean3_dev(x, do_round=True, out=None):
+    out = out or DeviceRaster.empty(x.shape, x.dtype, x.ctx)
+    c = x.ctx
+    fn = (c.lib.hdem_boxmean3_f32_dev if x.dtype == np.float32
+          else c.lib.hdem_boxmean3_f64_dev)
+    if x.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError(f"box mean needs a float raster, got {x.dtype}")
+    c.check(fn(c.handle, x.ptr, x.shape[0], x.shape[1], int(bool(do_round)), out.ptr))
+    return out
+
+
+def quadratic_dev(dem, window_size=15, out=None):
+    _need(dem, np.float32)
+    out = out or DeviceRaster.empty(dem.shape, np.float32, dem.ctx)
+    c = dem.ctx
+    c.check(c.lib.hdem_quadratic_f32_dev(c.handle, dem.ptr, dem.shape[0],
+                                         dem.shape[1], int(window_size), out.ptr),
+            window=window_size, shape=dem.shape)
+    return out
+
+
+def groves_dev(img, groves, window_size=15, threshold=1.5, iterations=3, out=None):
+    _need(img, np.float32)
+    _need(groves, np.uint8)
+    c = img.ctx
+    out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    scratch = DeviceRaster.empty(img.shape, np.float32, c) if iterations > 1 else None
+    try:
+        c.check(c.lib.hdem_groves_f32_dev(c.handle, img.ptr, groves.ptr, img.shape[0],
+                                          img.shape[1], int(window_size),
+                                          float(threshold), int(iterations),
+                                          scratch.ptr if scratch else None, out.ptr),
+                window=window_size, shape=img.shape)
+    finally:
+        if scratch is not None:
+            c.synchronize()
+            scratch.free()
+    return out
+
+
+# ---------------------------------------------------------------------------
+# host-array operators (what Filter.apply binds): NumPy in, NumPy out
+# ---------------------------------------------------------------------------
+
+def _host2d(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.ndim != 2:
+        raise ValueError(f"expected a 2-D raster, got shape {a.shape}")
+    return a
+
+
+def d8(z):
+    c = context()
+    z = _host2d(z, np.float32)
+    out = np.empty(z.shape, np.uint8)
+    c.check(c.lib.hdem_d8_f32(c.handle, z.ctypes.data, z.shape[0], z.shape[1],
+                              out.ctypes.data))
+    return out
+
+
+def sinkfill(z, eps=0.0, max_rounds=0, return_stats=False):
+    c = context()
+    z = _host2d(z, np.float32)
+    out = np.empty_like(z)
+    st = FillStats()
+    c.check(c.lib.hdem_sinkfill_f32(c.handle, z.ctypes.data, z.shape[0], z.shape[1],
+                                    float(eps), int(max_rounds), out.ctypes.data,
+                                    ctypes.byref(st)))
+    return (out, st.as_dict()) if return_stats else out
+
+
+def boxmean3(x, do_round=True):
+    c = context()
+    if np.asarray(x).dtype == np.float32:
+        x = _host2d(x, np.float32)
+        fn = c.lib.hdem_boxmean3_f32
+    else:
+        x = _host2d(x, np.float64)
+        fn = c.lib.hdem_boxmean3_f64
+    out = np.empty_like(x)
+    c.check(fn(c.handle, x.ctypes.data, x.shape[0], x.shape[1], int(bool(do_round)),
+               out.ctypes.data))
+    return out
+
+
+def convolve(x, weights):
+    c = context()
+    x = _host2d(x, np.float32)
+    w = _host2d(weights, np.float64)
+    out = np.empty_like(x)
+    c.check(c.lib.hdem_convolve_f32(c.handle, x.ctypes.data, x.shape[0], x.shape[1],
+                                    w.ctypes.data, w.shape[0], w.shape[1],
+                                    out.ctypes.data))
+    return out
+
+
+def around(x):
+    c = context()
+    if np.asarray(x).dtype == np.float32:
+        a, fn = np.ascontiguousarray(x, dtype=np.float32), c.lib.hdem_around_f32
+    else:
+        a, fn = np.ascontiguousarray(x, dtype=np.float64), c.lib.hdem_around_f64
+    out = np.empty_like(a)
+    if a.size:
+        c.check(fn(c.handle, a.ctypes.data, a.size, out.ctypes.data))
+    return out
+
+
+def quadratic(dem, window_size=15):
+    c = context()
+    dem = _host2d(dem, np.float32)
+    out = np.empty_like(dem)
+    c.check(c.lib.hdem_quadratic_f32(c.handle, dem.ctypes.data, dem.shape[0],
+                                     dem.shape[1], int(window_size), out.ctypes.data),
+            window=window_size, shape=dem.shape)
+    return out
+
+
+def groves(img, groves_class, window_size=15, threshold=1.5, iterations=1):
+    c = context()
+    img = _host2d(img, np.float32)
+    g = _host2d(np.asarray(groves_class) != 0, np.uint8)
+    if g.shape != img.shape:
+        raise ValueError(f"groves class shape {g.shape} != image shape {img.shape}")
+    out = np.empty_like(img)
+    c.check(c.lib.hdem_groves_f32(c.handle, img.ctypes.data, g.ctypes.data,
+                                  img.shape[0], img.shape[1], int(window_size),
+                                  float(threshold), int(iterations), out.ctypes.data),
+            window=window_size, shape=img.shape)
+    return out
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = HydroDEMException  # re-exported for callers that catch the base class

@@ -1,0 +1,210 @@
+// Context, memory, error and profiling plumbing of libhydrodem_hip.so.
+#include "hdem_internal.h"
+
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void hdem_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *hdem_last_error(void) { return g_err; }
+extern "C" int hdem_version(void) { return 100; }
+
+extern "C" int hdem_device_count(int *count)
+{
+    HDEM_REQUIRE(count, HDEM_ERR_BAD_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        hdem_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return HDEM_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_init(int device, hdem_ctx **out)
+{
+    HDEM_REQUIRE(out, HDEM_ERR_BAD_ARG, "ctx out-pointer is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        hdem_set_error("no HIP device visible");
+        return HDEM_ERR_NO_DEVICE;
+    }
+    HDEM_REQUIRE(device >= 0 && device < n, HDEM_ERR_BAD_ARG,
+                 "device %d out of range [0, %d)", device, n);
+    HDEM_HIP_CHECK(hipSetDevice(device));
+    hdem_ctx *ctx = new (std::nothrow) hdem_ctx();
+    HDEM_REQUIRE(ctx, HDEM_ERR_OOM, "out of host memory");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        hdem_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return HDEM_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_shutdown(hdem_ctx *ctx)
+{
+    if (!ctx) return HDEM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->pending) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
+    if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_set_stream(hdem_ctx *ctx, void *hip_stream)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_synchronize(hdem_ctx *ctx)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr)
+{
+    HDEM_REQUIRE(ctx && dptr, HDEM_ERR_BAD_ARG, "null argument");
+    *dptr = nullptr;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_free(hdem_ctx *ctx, void *dptr)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (!dptr) return HDEM_OK;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HDEM_HIP_CHECK(hipFree(dptr));
+    return HDEM_OK;
+}
+
+static int copy_sync(hdem_ctx *ctx, void *dst, const void *src, size_t bytes,
+                     hipMemcpyKind kind)
+{
+    HDEM_REQUIRE(ctx && (bytes == 0 || (dst && src)), HDEM_ERR_BAD_ARG,
+                 "null argument");
+    if (!bytes) return HDEM_OK;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    if (kind != hipMemcpyDeviceToDevice)
+        HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_memcpy_h2d(hdem_ctx *c, void *d, const void *s, size_t n)
+{ return copy_sync(c, d, s, n, hipMemcpyHostToDevice); }
+extern "C" int hdem_memcpy_d2h(hdem_ctx *c, void *d, const void *s, size_t n)
+{ return copy_sync(c, d, s, n, hipMemcpyDeviceToHost); }
+extern "C" int hdem_memcpy_d2d(hdem_ctx *c, void *d, const void *s, size_t n)
+{ return copy_sync(c, d, s, n, hipMemcpyDeviceToDevice); }
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+static hipEvent_t take_event(hdem_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t ev = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+hdem_scoped_timer::hdem_scoped_timer(hdem_ctx *c, int kernel_id, int64_t units)
+    : ctx(c), on(c && c->profiling)
+{
+    if (!on) return;
+    t.kernel_id = kernel_id;
+    t.units = units;
+    t.start = take_event(ctx);
+    t.stop = take_event(ctx);
+    if (!t.start || !t.stop) { on = false; return; }
+    (void)hipEventRecord(t.start, ctx->stream);
+}
+
+hdem_scoped_timer::~hdem_scoped_timer()
+{
+    if (!on) return;
+    (void)hipEventRecord(t.stop, ctx->stream);
+    ctx->pending.push_back(t);
+}
+
+int hdem_fold_profile(hdem_ctx *ctx)
+{
+    if (ctx->pending.empty()) return HDEM_OK;
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            hdem_kernel_stat &s = ctx->stats[t.kernel_id];
+            s.launches += 1;
+            s.ms += ms;
+            s.units += t.units;
+        }
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->pending.clear();
+    return HDEM_OK;
+}
+
+extern "C" int hdem_profile_enable(hdem_ctx *ctx, int on)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    ctx->profiling = on != 0;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_profile_reset(hdem_ctx *ctx)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    int rc = hdem_fold_profile(ctx);
+    std::memset(ctx->stats, 0, sizeof(ctx->stats));
+    return rc;
+}
+
+extern "C" int hdem_profile_get(hdem_ctx *ctx, int kernel_id, hdem_kernel_stat *out)
+{
+    HDEM_REQUIRE(ctx && out, HDEM_ERR_BAD_ARG, "null argument");
+    HDEM_REQUIRE(kernel_id >= 0 && kernel_id < HDEM_K_COUNT, HDEM_ERR_BAD_ARG,
+                 "kernel id %d out of range", kernel_id);
+    int rc = hdem_fold_profile(ctx);
+    *out = ctx->stats[kernel_id];
+    return rc;
+}

@@ -1,0 +1,116 @@
+// Internal declarations shared by the .hip translation units of
+// libhydrodem_hip.so.  Nothing here is part of the C ABI (include/hydrodem_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/hydrodem_hip.h"
+
+void hdem_set_error(const char *fmt, ...);
+
+#define HDEM_HIP_CHECK(expr)                                                  \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) {                                               \
+            hdem_set_error("%s failed: %s (%s:%d)", #expr,                    \
+                           hipGetErrorString(e_), __FILE__, __LINE__);        \
+            return e_ == hipErrorOutOfMemory ? HDEM_ERR_OOM : HDEM_ERR_HIP;   \
+        }                                                                     \
+    } while (0)
+
+#define HDEM_REQUIRE(cond, code, ...)                                         \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            hdem_set_error(__VA_ARGS__);                                      \
+            return (code);                                                    \
+        }                                                                     \
+    } while (0)
+
+struct hdem_timed_launch {
+    hipEvent_t start, stop;
+    int kernel_id;
+    int64_t units;
+};
+
+struct hdem_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;      // stream in use (own or caller's)
+    int num_cus = 256;
+    bool profiling = false;
+    std::vector<hdem_timed_launch> pending;   // events not yet folded in
+    std::vector<hipEvent_t> event_pool;
+    hdem_kernel_stat stats[HDEM_K_COUNT] = {};
+    // sink-fill workspace (grown on demand, reused across calls)
+    void *fill_ws = nullptr;
+    size_t fill_ws_bytes = 0;
+    int32_t *host_counts = nullptr;    // pinned: convergence counters
+    size_t host_counts_len = 0;
+};
+
+// Brackets one kernel launch with events when profiling is on.
+struct hdem_scoped_timer {
+    hdem_ctx *ctx;
+    bool on;
+    hdem_timed_launch t;
+    hdem_scoped_timer(hdem_ctx *c, int kernel_id, int64_t units);
+    ~hdem_scoped_timer();
+};
+
+int hdem_fold_profile(hdem_ctx *ctx);   // sync + accumulate pending events
+
+static inline int hdem_check_raster(const void *in, const void *out, int H,
+                                    int W)
+{
+    if (!in || !out) {
+        hdem_set_error("null raster pointer");
+        return HDEM_ERR_BAD_ARG;
+    }
+    if (H <= 0 || W <= 0) {
+        hdem_set_error("raster dimensions must be positive, got %d x %d", H, W);
+        return HDEM_ERR_BAD_ARG;
+    }
+    return HDEM_OK;
+}
+
+// Host-pointer wrapper helper: device buffer that frees itself.
+struct hdem_dbuf {
+    void *p = nullptr;
+    ~hdem_dbuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            p = nullptr;
+            hdem_set_error("hipMalloc(%zu) failed: %s", bytes,
+                           hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? HDEM_ERR_OOM : HDEM_ERR_HIP;
+        }
+        return HDEM_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#define HDEM_INF (__builtin_huge_valf())
+
+// 16-byte vector of 4 floats with only 4-byte alignment assumed, so that a
+// row whose pitch is not a multiple of 16 B can still be moved with one
+// global_load_dwordx4 / global_store_dwordx4 per lane.
+typedef float hdem_f4 __attribute__((ext_vector_type(4)));
+typedef float hdem_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ hdem_f4 hdem_ld4u(const float *p)
+{
+    return *reinterpret_cast<const hdem_f4u *>(p);
+}
+__device__ __forceinline__ void hdem_st4u(float *p, hdem_f4 v)
+{
+    *reinterpret_cast<hdem_f4u *>(p) = v;
+}

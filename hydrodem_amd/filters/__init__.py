@@ -46,20 +46,26 @@ class ComposedFilter(Filter):  # pylint: disable=too-few-public-methods
 
     def apply(self, image_to_filter):
         Filter.apply(self, image_to_filter)
-        if _device_chain(self.filters):
+        if (_device_chain(self.filters) and image_to_filter.ndim == 2
+                and image_to_filter.dtype == "float32"):
             from ..backend import DeviceRaster
             with DeviceRaster.from_host(image_to_filter) as raster:
-                return self.apply_device(raster).to_host()
+                with self.apply_device(raster) as result:
+                    return result.to_host()
         content = image_to_filter
         for filter_ in self.filters:
             content = filter_.apply(content)
         return content
 
     def apply_device(self, raster):
-        """Chain on a device-resident raster (consumes ``raster``)."""
+        """Chain on a device-resident raster; the caller keeps ownership of
+        ``raster`` and receives a new one."""
         content = raster
         for filter_ in self.filters:
-            content = filter_.apply_device(content)
+            following = filter_.apply_device(content)
+            if content is not raster and content is not following:
+                content.free()      # intermediate of this chain
+            content = following
         return content
 
 

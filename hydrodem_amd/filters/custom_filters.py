@@ -1,0 +1,238 @@
+"""
+Stencil operators of the hot path, backed by the HIP library.
+
+Reference twins (`cguerrero/hydrodem/filters/custom_filters.py`):
+``QuadraticFilter`` :202-257, ``MaskTallGroves`` :513-534,
+``GrovesCorrection`` :664-732, ``GrovesCorrectionsIter`` :735-767,
+``PostProcessingFinal`` :1104-1125 -- same class names, constructor
+signatures, mutable operand attributes and error classes.
+
+New operators (the reference has neither): ``SinkFill`` and
+``D8FlowDirection``, shaped like every other ``Filter``.
+
+Storage type.  The device path stores rasters as float32 (what GDAL hands the
+reference, `image_srtm.py:125`).  The reference drifts to float64 after the
+first groves pass (float32 * int64); the values agree to <= 1 float32 ulp and
+every reference stencil re-reads its input through ``astype('float32')``
+anyway (`sliding_window.py:132`).
+"""
+
+import numpy as np
+
+from . import Filter, ComposedFilter
+from .simple_filters import (GreaterThan, BooleanToInteger, ProductFilter,
+                             SubtractionFilter)
+from .extension_filters import Convolve, Around
+from .. import backend
+
+
+class QuadraticFilter(Filter):  # pylint: disable=too-few-public-methods
+    """Least-squares quadratic smoothing over a ``window_size`` square window;
+    the ring of ``window_size // 2`` cells is returned unchanged
+    (custom_filters.py:202-257).  Window validation raises the same
+    ``WindowSizeHighError`` / ``WindowSizeEvenError`` as the reference's
+    ``SlidingWindow`` constructor (sliding_window.py:150-156)."""
+
+    def __init__(self, *, window_size):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        return backend.quadratic(image_to_filter, self.window_size)
+
+    def apply_device(self, raster):
+        return backend.quadratic_dev(raster, self.window_size)
+
+
+class MaskTallGroves(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """``(image > 1.5) * 1`` (custom_filters.py:513-534).  Host NumPy; inside
+    ``GrovesCorrection`` this algebra runs in the fused kernel's epilogue."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [GreaterThan(value=1.5), BooleanToInteger()]
+
+
+class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """One groves correction pass (custom_filters.py:664-732):
+
+        smooth = QuadraticFilter(15)(img); hl = img - smooth
+        m = groves_class * (hl > 1.5);     out = hl * (1 - m) + smooth
+
+    evaluated by ONE fused HIP kernel.  ``filters`` keeps the reference's five
+    members so that callers can still re-bind their operands
+    (``filters[3].factor`` is the groves class, ``filters[0].window_size`` the
+    window, ``filters[2].filters[0].value`` the tall-grove threshold); they
+    are read at ``apply`` time.  ``partial_results`` is filled only with
+    ``keep_partial_results=True`` (it costs an extra quadratic pass)."""
+
+    def __init__(self, groves_class, keep_partial_results=False):  # pylint: disable=super-init-not-called
+        self.partial_results = []
+        self.keep_partial_results = keep_partial_results
+        self.filters = [QuadraticFilter(window_size=15), SubtractionFilter(),
+                        MaskTallGroves(), ProductFilter(factor=groves_class),
+                        SubtractionFilter(minuend=1)]
+
+    def _params(self):
+        return (self.filters[3].factor, self.filters[0].window_size,
+                self.filters[2].filters[0].value)
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        groves_class, window, thr = self._params()
+        if self.keep_partial_results:
+            img = np.ascontiguousarray(image_to_filter, dtype=np.float32)
+            smooth = backend.quadratic(img, window)
+            highlight = img - smooth
+            tall = (highlight > thr) * 1
+            product = groves_class * tall
+            self.partial_results = [smooth, highlight, tall, product, 1 - product]
+        return backend.groves(image_to_filter, groves_class, window, thr, 1)
+
+    def apply_device(self, raster):
+        groves_class, window, thr = self._params()
+        with backend.DeviceRaster.from_host(np.asarray(groves_class) != 0,
+                                            dtype=np.uint8, ctx=raster.ctx) as g:
+            out = backend.groves_dev(raster, g, window, thr, 1)
+            raster.ctx.synchronize()
+        return out
+
+
+class GrovesCorrectionsIter(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """``iterations`` chained ``GrovesCorrection`` passes
+    (custom_filters.py:735-767).  When the members are untouched the whole
+    chain is one C call that ping-pongs two device buffers."""
+
+    def __init__(self, groves_class, iterations=3):  # pylint: disable=super-init-not-called
+        self.filters = []
+        for _ in range(iterations):
+            self.filters.append(GrovesCorrection(groves_class))
+
+    def _uniform(self):
+        if not self.filters or not all(type(f) is GrovesCorrection and
+                                       not f.keep_partial_results
+                                       for f in self.filters):
+            return None
+        p0 = self.filters[0]._params()
+        for f in self.filters[1:]:
+            p = f._params()
+            if p[0] is not p0[0] or p[1:] != p0[1:]:
+                return None
+        return p0
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        params = self._uniform()
+        if params is None:
+            return ComposedFilter.apply(self, image_to_filter)
+        groves_class, window, thr = params
+        return backend.groves(image_to_filter, groves_class, window, thr,
+                              len(self.filters))
+
+    def apply_device(self, raster):
+        params = self._uniform()
+        if params is None:
+            return ComposedFilter.apply_device(self, raster)
+        groves_class, window, thr = params
+        with backend.DeviceRaster.from_host(np.asarray(groves_class) != 0,
+                                            dtype=np.uint8, ctx=raster.ctx) as g:
+            out = backend.groves_dev(raster, g, window, thr, len(self.filters))
+            raster.ctx.synchronize()
+        return out
+
+
+class PostProcessingFinal(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """3x3 box mean then round to 1 m (custom_filters.py:1104-1125).  With the
+    default members the two run as one fused kernel (float32 or float64)."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [Convolve(), Around()]
+
+    def _fused(self):
+        return (len(self.filters) == 2 and type(self.filters[0]) is Convolve
+                and self.filters[0]._is_box3() and type(self.filters[1]) is Around)
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        if self._fused():
+            return backend.boxmean3(image_to_filter, do_round=True)
+        content = image_to_filter
+        for filter_ in self.filters:
+            content = filter_.apply(content)
+        return content
+
+    def apply_device(self, raster):
+        if not self._fused():
+            raise NotImplementedError("device chain needs the default members")
+        return backend.boxmean3_dev(raster, do_round=True)
+
+
+class SinkFill(Filter):  # pylint: disable=too-few-public-methods
+    """Depression filling (new operator; normative definition SURVEY 8a A1).
+
+    ``W = max(Z, spill elevation)``: the greatest fixed point of
+    ``W[c] = max(Z[c], min(W[c], min8(W[n] + epsilon)))`` with the one-cell
+    border pinned to Z ("interior only, border untouched", the convention of
+    `sliding_window.py:187-192`); nodata (NaN) cells stay NaN and act as
+    outlets.  ``epsilon = 0`` gives flats and is bit-reproducible.
+
+    Attributes
+    ----------
+    epsilon : float
+        Planchon-Darboux gradient added per step (metres), default 0.
+    max_rounds : int
+        Worklist-round limit; 0 = library default.  ``NotConvergedError`` when
+        it is hit.
+    stats : dict
+        rounds / tile_visits / tiles of the last ``apply``.
+    """
+
+    def __init__(self, *, epsilon=0.0, max_rounds=0):
+        self.epsilon = epsilon
+        self.max_rounds = max_rounds
+        self.stats = {}
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        out, self.stats = backend.sinkfill(image_to_filter, self.epsilon,
+                                           self.max_rounds, return_stats=True)
+        return out
+
+    def apply_device(self, raster):
+        out, self.stats = backend.sinkfill_dev(raster, self.epsilon, self.max_rounds)
+        return out
+
+
+class D8FlowDirection(Filter):  # pylint: disable=too-few-public-methods
+    """D8 steepest-descent direction (new operator): ESRI codes
+    E=1, SE=2, S=4, SW=8, W=16, NW=32, N=64, NE=128, 0 = no lower neighbour or
+    border cell; drop = (z_c - z_k) / distance evaluated in float32 as
+    ``(z_c - z_k) * w_k``, w = 1 or float32(0.70710678); ties go to the first
+    neighbour in window order NW, N, NE, W, E, SW, S, SE (the order
+    ``np.nonzero`` gives `custom_filters.py:193-195`).  Returns uint8."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return backend.d8(image_to_filter)
+
+    def apply_device(self, raster):
+        return backend.d8_dev(raster)
+
+
+class HydroConditioning(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """``SinkFill`` then ``D8FlowDirection`` as one device-resident chain (the
+    pair BASELINE.json's metric is quoted on).  ``filled`` keeps the filled
+    DEM of the last ``apply``; the return value is the D8 grid."""
+
+    def __init__(self, *, epsilon=0.0):
+        super().__init__()
+        self.filters = [SinkFill(epsilon=epsilon), D8FlowDirection()]
+        self.filled = None
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        with backend.DeviceRaster.from_host(image_to_filter, dtype=np.float32) as z:
+            with self.filters[0].apply_device(z) as filled:
+                with self.filters[1].apply_device(filled) as codes:
+                    filled.ctx.synchronize()
+                    self.filled = filled.to_host()
+                    return codes.to_host()

@@ -1,0 +1,163 @@
+/*
+ * hydrodem_hip.h -- C ABI of the MI355X (gfx950) raster hot path.
+ *
+ * This is the drop-in boundary: plain C, caller-owned pointers and sizes, no
+ * C++ or torch types, no exceptions.  Every operator entry point replaces the
+ * body of one `Filter.apply(ndarray) -> ndarray` of the reference package
+ * (`cguerrero/hydrodem/filters/__init__.py:23-39`); the reference-side ctypes
+ * stub that binds it is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - rasters are C-contiguous row-major, H rows x W columns;
+ *   - every function returns an hdem_status; on failure hdem_last_error()
+ *     (thread local) holds a message.  Window validation uses the same two
+ *     failure classes as `sliding_window.py:150-156`
+ *     (HDEM_ERR_WINDOW_HIGH / HDEM_ERR_WINDOW_EVEN);
+ *   - `*_f32(...)` entry points take HOST pointers, run synchronously
+ *     (upload, kernels, download) and never keep or free caller memory;
+ *   - `*_dev(...)` entry points take DEVICE pointers, enqueue on the context's
+ *     stream and return without synchronising (except sink fill, which has to
+ *     read its convergence counter);
+ *   - there is no CPU fallback anywhere behind this header.
+ */
+#ifndef HYDRODEM_HIP_H
+#define HYDRODEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hdem_ctx hdem_ctx;
+
+typedef enum hdem_status {
+    HDEM_OK = 0,
+    HDEM_ERR_BAD_ARG = 1,       /* null pointer, non-positive size, ...      */
+    HDEM_ERR_WINDOW_EVEN = 2,   /* -> WindowSizeEvenError                    */
+    HDEM_ERR_WINDOW_HIGH = 3,   /* -> WindowSizeHighError                    */
+    HDEM_ERR_HIP = 4,           /* a HIP runtime call failed                 */
+    HDEM_ERR_NOT_CONVERGED = 5, /* sink fill hit max_rounds                  */
+    HDEM_ERR_NO_DEVICE = 6,
+    HDEM_ERR_OOM = 7
+} hdem_status;
+
+/* ---- life cycle -------------------------------------------------------- */
+const char *hdem_last_error(void);
+int hdem_version(void);                       /* 100*major + minor          */
+int hdem_device_count(int *count);
+int hdem_init(int device, hdem_ctx **ctx);    /* own stream + workspace     */
+int hdem_shutdown(hdem_ctx *ctx);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream);
+ * NULL restores the context's own stream. */
+int hdem_set_stream(hdem_ctx *ctx, void *hip_stream);
+int hdem_synchronize(hdem_ctx *ctx);
+
+/* ---- device memory (so that a host needs nothing but this library) ------ */
+int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr);
+int hdem_free(hdem_ctx *ctx, void *dptr);
+int hdem_memcpy_h2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+int hdem_memcpy_d2h(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+int hdem_memcpy_d2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- per-kernel timing (HIP events on the stream the kernels run on) ---- */
+typedef enum hdem_kernel_id {
+    HDEM_K_D8 = 0,
+    HDEM_K_FILL_INIT = 1,
+    HDEM_K_FILL_TILE = 2,     /* the sink-fill tile relaxation (dominant)   */
+    HDEM_K_BOXMEAN = 3,
+    HDEM_K_GROVES = 4,        /* fused quadratic + groves epilogue          */
+    HDEM_K_CONVOLVE = 5,
+    HDEM_K_FILL_SCAN = 6,     /* directional upper-bound scans              */
+    HDEM_K_COUNT = 8
+} hdem_kernel_id;
+
+typedef struct hdem_kernel_stat {
+    int64_t launches;
+    double  ms;               /* sum of event-timed launch durations        */
+    int64_t units;            /* cells (or tile-visit cells) processed      */
+} hdem_kernel_stat;
+
+int hdem_profile_enable(hdem_ctx *ctx, int on);   /* default off            */
+int hdem_profile_reset(hdem_ctx *ctx);
+/* synchronises the stream, then reports the totals since the last reset */
+int hdem_profile_get(hdem_ctx *ctx, int kernel_id, hdem_kernel_stat *out);
+
+/* ---- A2  D8FlowDirection.apply  (new operator; no reference body --------
+ * SURVEY F2; tie rule of custom_filters.py:193-195).  ESRI codes, uint8. */
+int hdem_d8_f32(hdem_ctx *ctx, const float *z, int H, int W, uint8_t *out);
+int hdem_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, uint8_t *out);
+
+/* ---- A1  SinkFill.apply  (new operator; no reference body -- SURVEY F2) -- */
+typedef struct hdem_fill_stats {
+    int32_t rounds;           /* worklist rounds executed                    */
+    int32_t converged;        /* 1 when the worklist drained                 */
+    int64_t tile_visits;      /* tiles relaxed, summed over rounds           */
+    int64_t tiles;            /* tiles in the raster                         */
+    int32_t tile_h, tile_w;   /* tile shape in cells                         */
+    int32_t scans;            /* directional scan launches                   */
+    int32_t reserved;
+} hdem_fill_stats;
+
+#define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */
+#define HDEM_FILL_WARM        0x1  /* w holds a valid upper bound; the one-cell ring of w
+                                      is the Dirichlet boundary (never written)           */
+#define HDEM_FILL_ACT_ALL     0x0  /* WARM: every tile starts active                      */
+#define HDEM_FILL_ACT_TOP     0x2  /* WARM: only tiles touching row 1 ...                 */
+#define HDEM_FILL_ACT_BOTTOM  0x4  /* ... and/or row H-2 start active (after a halo       */
+                                   /* exchange replaced ghost row 0 / H-1)                */
+#define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
+
+/* eps = 0 gives flats (exact, order-independent, bit-reproducible);
+ * eps > 0 is the Planchon-Darboux gradient.  max_rounds <= 0 -> default. */
+int hdem_sinkfill_f32(hdem_ctx *ctx, const float *z, int H, int W, float eps,
+                      int max_rounds, float *w, hdem_fill_stats *stats);
+int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W,
+                          float eps, int max_rounds, int flags, float *w,
+                          hdem_fill_stats *stats);
+
+/* ---- A5  Convolve.apply + Around.apply -----------------------------------
+ * extension_filters.py:166-184 (scipy.ndimage.convolve, mode='reflect',
+ * double accumulation, result / weights.size) and :113-130 (np.around).
+ * boxmean3 is the ones((3,3)) default fused with the optional rounding
+ * (PostProcessingFinal, custom_filters.py:1124-1125). */
+int hdem_boxmean3_f32(hdem_ctx *ctx, const float *x, int H, int W,
+                      int do_round, float *out);
+int hdem_boxmean3_f64(hdem_ctx *ctx, const double *x, int H, int W,
+                      int do_round, double *out);
+int hdem_boxmean3_f32_dev(hdem_ctx *ctx, const float *x, int H, int W,
+                          int do_round, float *out);
+int hdem_boxmean3_f64_dev(hdem_ctx *ctx, const double *x, int H, int W,
+                          int do_round, double *out);
+/* general odd kh x kw weights (host pointer, row-major doubles), <= 15x15 */
+int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
+                      const double *weights, int kh, int kw, float *out);
+int hdem_around_f32(hdem_ctx *ctx, const float *x, int64_t n, float *out);
+int hdem_around_f64(hdem_ctx *ctx, const double *x, int64_t n, double *out);
+
+/* ---- A3  QuadraticFilter.apply  (custom_filters.py:226-257) -------------
+ * ws odd and <= min(H, W) (sliding_window.py:150-156); border ring of ws/2
+ * cells is returned unchanged (custom_filters.py:249). */
+int hdem_quadratic_f32(hdem_ctx *ctx, const float *dem, int H, int W, int ws,
+                       float *out);
+int hdem_quadratic_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W,
+                           int ws, float *out);
+
+/* ---- A4  GrovesCorrection / GrovesCorrectionsIter.apply -----------------
+ * custom_filters.py:708-732,755-767 with MaskTallGroves :533-534 fused:
+ *   smooth = quadratic(img); hl = img - smooth; m = groves && hl > thr;
+ *   out = m ? smooth : hl + smooth;   repeated `iters` times.
+ * groves: uint8, non-zero = groves class.  scratch_dev (iters > 1) is a
+ * second H*W float device buffer for the ping-pong; may be NULL for the
+ * host-pointer variant. */
+int hdem_groves_f32(hdem_ctx *ctx, const float *img, const uint8_t *groves,
+                    int H, int W, int ws, float thr, int iters, float *out);
+int hdem_groves_f32_dev(hdem_ctx *ctx, const float *img, const uint8_t *groves,
+                        int H, int W, int ws, float thr, int iters,
+                        float *scratch_dev, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRODEM_HIP_H */
