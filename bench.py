@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the hot path's headline metric on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S]
+
+Metric (BASELINE.json): Mcells/s of SinkFill (to convergence) + D8FlowDirection
+on a 16384^2 float32 DEM, inputs resident in HBM when the timed region starts,
+outputs left in HBM.  One "step" = one full sink fill + D8 of the raster.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the raster
+is N*S rows x S columns, row-block partitioned, S rows per rank -- weak
+scaling -- with halo exchange between local solves (hydrodem_amd/partition.py).
+
+One JSON line on stdout (rank 0) with, besides the contract keys:
+  roofline      dominant kernel = the sink-fill tile relaxation: algorithmic
+                bytes (12 B per cell of every tile visit: Z in, W in, W out)
+                / its HIP-event time over the timed steps, vs 8 TB/s HBM peak;
+  kernels       the same for D8 (5 B/cell) and the init kernel;
+  cpu_baseline  the NumPy oracle (sink fill Jacobi to convergence + D8,
+                1 thread) on a bounded crop of the same DEM, same host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FILL_BYTES_PER_CELL = 12    # per tile visit: Z in + W in + W out
+D8_BYTES_PER_CELL = 5
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--size", type=int, default=16384)
+    p.add_argument("--cpu-sample", type=int, default=1024,
+                   help="edge of the crop the CPU oracle is timed on (0 = skip)")
+    return p.parse_args()
+
+
+def cpu_baseline(z_crop):
+    """NumPy oracle (the 'NumPy CPU reference' of north_star) on a crop of the
+    workload; checker code timed as a baseline, never used as product."""
+    import oracle
+    from oracle import c_oracle
+    n = z_crop.size
+    t = time.perf_counter()
+    w, sweeps = oracle.sinkfill_jacobi(z_crop)
+    oracle.d8_flow_direction(w)
+    dt = time.perf_counter() - t
+    t = time.perf_counter()
+    w2 = c_oracle.sinkfill_pflood(z_crop)
+    c_oracle.d8(w2)
+    dt_c = time.perf_counter() - t
+    assert np.array_equal(w, w2)
+    return {"value": n / dt / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": f"{z_crop.shape[0]}x{z_crop.shape[1]} crop (rows/cols 0..) of the "
+                      f"workload DEM; NumPy Jacobi sink fill to convergence "
+                      f"({sweeps} sweeps) + NumPy D8, single thread, {dt:.1f} s",
+            "host_cores": os.cpu_count(),
+            "c_priority_flood": {"value": n / dt_c / 1e6, "unit": "Mcells/s", "cores": 1,
+                                 "seconds": dt_c,
+                                 "note": "same crop, C priority-flood oracle + C D8 "
+                                         "(a better CPU algorithm than the NumPy path)"}}
+
+
+def main():
+    a = parse()
+    S, N = a.size, a.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if N > 1 and world != N:
+        raise SystemExit(f"--gpus {N} needs torch.distributed.run with {N} ranks "
+                         f"(WORLD_SIZE={world})")
+
+    import oracle
+    from hydrodem_amd import backend as B
+
+    if N == 1:
+        ctx = B.context(0)
+        z = oracle.synth_dem(S, S)
+        zd = B.DeviceRaster.from_host(z, ctx=ctx)
+        wd = B.DeviceRaster.empty(z.shape, np.float32, ctx)
+        dd = B.DeviceRaster.empty(z.shape, np.uint8, ctx)
+        info = {}
+
+        def step():
+            _, st = B.sinkfill_dev(zd, out=wd)
+            B.d8_dev(wd, out=dd)
+            info.update(st)
+
+        def sync():
+            ctx.synchronize()
+
+        def reduce_max(x):
+            return x
+    else:
+        import torch
+        import torch.distributed as dist
+        from hydrodem_amd import partition as P
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+        H = N * S
+        g0, g1, top, bottom = P.local_range(rank, world, H)
+        z = oracle.synth_dem(H, S, row0=g0, rows=g1 - g0)
+        dev = torch.device("cuda", local_rank)
+        zt = torch.from_numpy(z).to(dev)
+        wt = torch.empty_like(zt)
+        dt_ = torch.empty(zt.shape, dtype=torch.uint8, device=dev)
+        solver = P.HipLocalSolver(local_rank)
+        ctx = solver.ctx
+        info = {}
+
+        def step():
+            _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt)
+            P.d8_distributed(wt, solver, out=dt_)
+            info.update(st)
+
+        def sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def reduce_max(x):
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+    for _ in range(a.warmup):
+        step()
+    ctx.profile(True)
+    ctx.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    elapsed = reduce_max(time.perf_counter() - t0)
+
+    kt = ctx.profile_get(B.K_FILL_TILE)
+    ki = ctx.profile_get(B.K_FILL_INIT)
+    k8 = ctx.profile_get(B.K_D8)
+    ctx.profile(False)
+
+    if rank == 0:
+        cells_total = N * S * S
+        ms_per_step = elapsed / a.steps * 1e3
+        fill_gbs = FILL_BYTES_PER_CELL * kt["units"] / max(kt["ms"], 1e-9) / 1e6
+        d8_gbs = D8_BYTES_PER_CELL * k8["units"] / max(k8["ms"], 1e-9) / 1e6
+        out = {
+            "metric": "Mcells/s sink-fill+D8 on 16384^2 float32 DEM",
+            "value": cells_total * a.steps / elapsed / 1e6,
+            "unit": "Mcells/s",
+            "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{N * S}x{S} float32 synthetic DEM (SURVEY 8d 'rough': "
+                                   f"plane + 4 sinusoids + 0.5 m noise + 0.1% pits), "
+                                   f"SinkFill eps=0 to exact convergence + D8; "
+                                   f"{S} rows per GPU, row-block partition",
+                       "rows_per_gpu": S, "cols": S,
+                       "tile_visits_per_step": info.get("tile_visits"),
+                       "rounds": info.get("rounds"),
+                       "halo_exchanges": info.get("exchanges", 0)},
+            "roofline": {"bound": "hbm", "kernel": "fill_tile_kernel",
+                         "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fill_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "launches": kt["launches"], "ms_total": kt["ms"],
+                         "bytes_per_launch": FILL_BYTES_PER_CELL * kt["units"]
+                         / max(kt["launches"], 1),
+                         "avg_launch_ms": kt["ms"] / max(kt["launches"], 1),
+                         "note": "rank 0; algorithmic 12 B per cell of every tile visit"},
+            "kernels": {"d8_kernel": {"achieved": d8_gbs, "unit": "GB/s",
+                                      "frac": d8_gbs / HBM_PEAK_GBS,
+                                      "avg_launch_ms": k8["ms"] / max(k8["launches"], 1)},
+                        "fill_init_kernel": {"avg_launch_ms": ki["ms"] / max(ki["launches"], 1)}},
+        }
+        if a.cpu_sample and N == 1:
+            c = min(a.cpu_sample, S)
+            zc = np.ascontiguousarray(z[:c, :c])
+            out["cpu_baseline"] = cpu_baseline(zc)
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -253,12 +253,17 @@ __global__ __launch_bounds__(NT) void fill_tile_kernel(const float *__restrict__
 // One lane per cell; the 3x3 nodata probe is served by L1/L2.
 __global__ __launch_bounds__(NT) void fill_init_kernel(const float *__restrict__ z,
                                                       float *__restrict__ w, int H, int W,
-                                                      int tiles_x, int *tile_pinned)
+                                                      int tiles_x, int *tile_pinned,
+                                                      int ghost_top, int ghost_bottom)
 {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= (size_t)H * W) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const float zc = z[i];
+    // a ghost row belongs to the neighbouring row block: only its two border
+    // cells are pinned; the rest waits at +inf for the first halo exchange
+    const bool ghost = (ghost_top && y == 0) || (ghost_bottom && y == H - 1);
+    if (ghost && x != 0 && x != W - 1) { w[i] = zc != zc ? zc : HDEM_INF; return; }
     bool pin = y == 0 || y == H - 1 || x == 0 || x == W - 1 || zc != zc;
     if (!pin) {
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(NT) void fill_init_kernel(const float *__restrict__
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const float zn = z[(size_t)(y + dy) * W + (x + dx)];
-                pin |= zn != zn;
+                pin |= zn != zn;   // (a nodata cell in a ghost row pins too: it is nodata for its owner as well)
             }
     }
     w[i] = pin ? zc : HDEM_INF;
@@ -370,7 +375,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
             const size_t n = (size_t)H * W;
             hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT),
-                               0, st, z, w, H, W, ws.tiles_x, ws.tile_pinned);
+                               0, st, z, w, H, W, ws.tiles_x, ws.tile_pinned,
+                               flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);
         }
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(NT), 0, st,
                            ws.tile_pinned, ws.tiles_x, ws.tiles_y, ws.flag, ws.list[0],

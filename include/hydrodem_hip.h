@@ -108,6 +108,8 @@ typedef struct hdem_fill_stats {
 #define HDEM_FILL_ACT_BOTTOM  0x4  /* ... and/or row H-2 start active (after a halo       */
                                    /* exchange replaced ghost row 0 / H-1)                */
 #define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
+#define HDEM_FILL_GHOST_TOP   0x10 /* INIT: row 0 / row H-1 is a ghost row owned by the   */
+#define HDEM_FILL_GHOST_BOTTOM 0x20 /* neighbouring row block: starts at +inf, not at Z    */
 
 /* eps = 0 gives flats (exact, order-independent, bit-reproducible);
  * eps > 0 is the Planchon-Darboux gradient.  max_rounds <= 0 -> default. */

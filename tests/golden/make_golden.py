@@ -26,6 +26,7 @@ from filters.custom_filters import (QuadraticFilter, GrovesCorrection,  # noqa: 
                                     GrovesCorrectionsIter,
                                     PostProcessingFinal)
 from filters.extension_filters import Convolve, Around  # noqa: E402
+import sliding_window as ref_sw  # noqa: E402
 from oracle.hdem_oracle_np import synth_dem  # noqa: E402
 
 
@@ -87,6 +88,31 @@ def main():
          around_out=Around().apply(np.array(
              [[0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 3.5001]],
              dtype=np.float32)))
+
+    # --- A6 SlidingWindow family: every window the reference yields -----------
+    grid = np.arange(81).reshape((9, 9))
+    ones = (rng.random((9, 9)) < 0.3).astype(np.int64)
+    cases = {
+        "SlidingWindow_3": (ref_sw.SlidingWindow, (grid, 3), {}),
+        "SlidingWindow_5": (ref_sw.SlidingWindow, (grid, 5), {}),
+        "SlidingWindow_ones_3": (ref_sw.SlidingWindow, (ones, 3), {"iter_over_ones": True}),
+        "SlidingIgnoreBorder_3": (ref_sw.SlidingIgnoreBorder, (grid, 3), {}),
+        "CircularWindow_5": (ref_sw.CircularWindow, (grid, 5), {}),
+        "InnerWindow_5_3": (ref_sw.InnerWindow, (grid, 5, 3), {}),
+        "NoCenterWindow_3": (ref_sw.NoCenterWindow, (grid, 3), {}),
+        "IgnoreBorderInnerSliding_5_3": (ref_sw.IgnoreBorderInnerSliding, (grid, 5),
+                                         {"inner_size": 3}),
+    }
+    arrays = {"grid": grid, "ones": ones}
+    for name, (cls, args, kw) in cases.items():
+        wins, idx = [], []
+        for w, c in cls(*args, **kw):
+            wins.append(w)
+            idx.append(c)
+        arrays[name + "_windows"] = np.stack(wins)
+        arrays[name + "_centres"] = np.array(idx)
+        arrays[name + "_getitem"] = cls(*args, **kw)[4, 4]
+    save("sliding.npz", **arrays)
 
     # --- rasters held by the reference's own test suite ---------------------
     zf = zipfile.ZipFile(os.path.join(REF, "tests/resources/tests_expected.zip"))

@@ -325,3 +325,59 @@ def test_device_chain_one_upload(golden):
     got = chain.apply(g["img"])
     step = hd.GrovesCorrectionsIter(g["groves"], iterations=3).apply(g["img"])
     assert np.array_equal(got, hd.PostProcessingFinal().apply(step))
+
+
+# --------------------------------------------------------------------------
+# row-block partition on the HIP solver (virtual ranks: one process, one GPU;
+# the exchange itself is covered under gloo in tests/test_partition.py)
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("world,H,W", [(2, 300, 200), (3, 260, 330), (4, 1024, 512)])
+def test_virtual_rank_partition_on_hip(world, H, W):
+    torch = pytest.importorskip("torch")
+    from hydrodem_amd import partition as P
+    assert torch.cuda.is_available()
+    z = oracle.synth_dem(H, W)
+    solver = P.HipLocalSolver(0)
+    blocks = []
+    for r in range(world):
+        g0, g1, top, bot = P.local_range(r, world, H)
+        zt = torch.from_numpy(z[g0:g1].copy()).cuda()
+        blocks.append({"z": zt, "w": torch.empty_like(zt), "top": top, "bot": bot})
+    for b in blocks:
+        flags = backend.FILL_INIT | (backend.FILL_GHOST_TOP if b["top"] else 0) \
+            | (backend.FILL_GHOST_BOTTOM if b["bot"] else 0)
+        solver.fill(b["z"], b["w"], 0.0, flags)
+    for _ in range(1000):
+        torch.cuda.synchronize()
+        sends = [(b["w"][1].clone(), b["w"][-2].clone()) for b in blocks]
+        any_changed = False
+        for r, b in enumerate(blocks):
+            flags = backend.FILL_WARM
+            if b["top"]:
+                new = sends[r - 1][1]
+                if not torch.equal(new, b["w"][0]):
+                    b["w"][0].copy_(new)
+                    flags |= backend.FILL_ACT_TOP
+            if b["bot"]:
+                new = sends[r + 1][0]
+                if not torch.equal(new, b["w"][-1]):
+                    b["w"][-1].copy_(new)
+                    flags |= backend.FILL_ACT_BOTTOM
+            if flags != backend.FILL_WARM:
+                any_changed = True
+                torch.cuda.synchronize()
+                solver.fill(b["z"], b["w"], 0.0, flags)
+        if not any_changed:
+            break
+    torch.cuda.synchronize()
+    got = np.concatenate([b["w"][P.owned_slice(r, world)].cpu().numpy()
+                          for r, b in enumerate(blocks)])
+    want = c_oracle.sinkfill_pflood(z)
+    assert np.array_equal(got, want)
+    codes = []
+    for r, b in enumerate(blocks):
+        d = P.d8_distributed(b["w"], solver)
+        torch.cuda.synchronize()
+        codes.append(d[P.owned_slice(r, world)].cpu().numpy())
+    assert np.array_equal(np.concatenate(codes), c_oracle.d8(want))
+    solver.ctx.set_stream(None)

@@ -1,0 +1,109 @@
+"""
+CPU suite, part 4: the N > 1 path.  The row-block partition + halo exchange of
+`hydrodem_amd/partition.py` runs here under `gloo` with world sizes 2 and 3;
+the local block solver is injected, so on CPU it is the NumPy oracle (tests
+may use the oracle; the product path injects the HIP solver).  The result
+must equal the unpartitioned oracle bit for bit -- the sink-fill fixed point
+does not depend on the update order.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from oracle import c_oracle
+from hydrodem_amd import backend, partition as P
+
+
+class NumpyLocalSolver:
+    """Oracle-backed stand-in for HipLocalSolver (same two methods)."""
+
+    def fill(self, z, w, eps, flags):
+        zn, wn = z.numpy(), w.numpy()
+        if not flags & backend.FILL_WARM:
+            w0 = oracle.sinkfill_init(zn)
+            if flags & backend.FILL_GHOST_TOP:
+                w0[0, 1:-1] = np.where(np.isnan(zn[0, 1:-1]), zn[0, 1:-1], np.inf)
+            if flags & backend.FILL_GHOST_BOTTOM:
+                w0[-1, 1:-1] = np.where(np.isnan(zn[-1, 1:-1]), zn[-1, 1:-1], np.inf)
+            wn[:] = w0
+        sweeps = 0
+        while True:
+            new, changed = oracle.sinkfill_sweep(zn, wn, eps)
+            wn[:] = new
+            sweeps += 1
+            if changed == 0:
+                return sweeps
+
+    def d8(self, w, out):
+        out.numpy()[:] = oracle.d8_flow_direction(w.numpy())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, H, W, eps, variant, nodata, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g0, g1, _, _ = P.local_range(rank, world, H)
+        z = oracle.synth_dem(H, W, row0=g0, rows=g1 - g0, variant=variant)
+        if nodata:
+            full = oracle.synth_dem(H, W, variant=variant)
+            full[H // 2 - 3:H // 2 + 3, 10:20] = np.nan        # straddles a seam for world=2
+            z = full[g0:g1].copy()
+        zt = torch.from_numpy(z)
+        solver = NumpyLocalSolver()
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps)
+        d = P.d8_distributed(w, solver)
+        own = P.owned_slice(rank, world)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), w=w.numpy()[own], d=d.numpy()[own],
+                 exchanges=info["exchanges"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,eps,variant,nodata", [
+    (2, 96, 80, 0.0, "rough", False),
+    (2, 101, 64, 0.0, "srtm", False),
+    (3, 90, 70, 0.0, "rough", False),
+    (2, 64, 48, 1e-3, "rough", False),
+    (2, 80, 60, 0.0, "rough", True),
+])
+def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, H, W, eps, variant, nodata, str(tmp_path)),
+             nprocs=world, join=True)
+    z = oracle.synth_dem(H, W, variant=variant)
+    if nodata:
+        z[H // 2 - 3:H // 2 + 3, 10:20] = np.nan
+    want_w = c_oracle.sinkfill_pflood(z, eps=eps)
+    want_d = c_oracle.d8(want_w)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    got_w = np.concatenate([p["w"] for p in parts])
+    got_d = np.concatenate([p["d"] for p in parts])
+    assert got_w.shape == z.shape
+    assert np.array_equal(np.nan_to_num(got_w, nan=-1), np.nan_to_num(want_w, nan=-1))
+    assert np.array_equal(got_d, want_d)
+    assert all(int(p["exchanges"]) >= 2 for p in parts)     # information did cross the seam
+
+
+def test_row_ranges_tile_the_raster():
+    for world in (1, 2, 3, 8):
+        for H in (8, 17, 16384, 65536 + 5):
+            rows = [P.row_range(r, world, H) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == H
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            for r in range(world):
+                g0, g1, top, bot = P.local_range(r, world, H)
+                assert (top, bot) == (r > 0, r < world - 1)
+                assert g0 == rows[r][0] - top and g1 == rows[r][1] + bot
