@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--size", type=int, default=16384)
-    p.add_argument("--cpu-sample", type=int, default=1024,
+    p.add_argument("--cpu-sample", type=int, default=2048,
                    help="edge of the crop the CPU oracle is timed on (0 = skip)")
     return p.parse_args()
 

@@ -299,15 +299,17 @@ __global__ __launch_bounds__(NT) void fill_seed_kernel(const int *__restrict__ t
 
 // Round-0 worklist for WARM starts: all tiles, or the tile rows next to a
 // ghost row that a halo exchange just replaced.
-__global__ __launch_bounds__(NT) void fill_seed_rows_kernel(int tiles_x, int tiles_y, int mode,
-                                                           int *flag, int *list0,
+__global__ __launch_bounds__(NT) void fill_seed_rows_kernel(int tiles_x, int tiles_y, int H,
+                                                           int mode, int *flag, int *list0,
                                                            int *count0, int stamp)
 {
     const int t = blockIdx.x * NT + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int ty = t / tiles_x;
-    const bool act = mode == 0 || ((mode & HDEM_FILL_ACT_TOP) && ty == 0) ||
-                     ((mode & HDEM_FILL_ACT_BOTTOM) && ty == tiles_y - 1);
+    // a replaced ghost row can only move the row next to it: row 1 / row H-2
+    // (the ghost row itself may sit alone in the last tile row)
+    const bool act = mode == 0 || ((mode & HDEM_FILL_ACT_TOP) && ty == 1 / FT) ||
+                     ((mode & HDEM_FILL_ACT_BOTTOM) && ty == max(H - 2, 0) / FT);
     if (act) enqueue(t, stamp, flag, list0, count0);
 }
 
@@ -383,7 +385,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                            ws.counts, 1);
     } else {
         hipLaunchKernelGGL(fill_seed_rows_kernel, dim3(tile_blocks), dim3(NT), 0, st,
-                           ws.tiles_x, ws.tiles_y,
+                           ws.tiles_x, ws.tiles_y, H,
                            flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM), ws.flag,
                            ws.list[0], ws.counts, 1);
     }
