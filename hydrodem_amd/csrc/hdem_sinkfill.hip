@@ -7,256 +7,627 @@
 // starts from an upper bound of W* and keeps visiting every cell converges to
 // the same bits: every value ever written is T applied to upper bounds, hence
 // itself an upper bound, and a state that no update changes is a fixed point
-// <= W*.  That licence is what the kernel below uses: tiles are relaxed
-// asynchronously, halos may be stale, in-register Gauss-Seidel replaces Jacobi.
+// <= W*.  That licence is what this file uses: tiles are relaxed
+// asynchronously, halos may be stale, directional Gauss-Seidel scans replace
+// Jacobi sweeps -- and a final round-synchronous pass certifies the fixed point.
 //
-// Schedule (gfx950):
-//   * the raster is cut into 64 x 64 cell tiles; a worklist holds the tiles
-//     whose halo changed since they were last relaxed;
-//   * one 256-thread workgroup relaxes one tile per visit: every lane owns a
-//     4 x 4 cell block -- its Z and W stay in VGPRs for the whole visit (32
-//     registers), loaded/stored as 16-byte row pieces (a wave moves 4 x 256 B
-//     contiguous runs per instruction);
-//   * lanes exchange only block perimeters through LDS, laid out as 16 planes
-//     (one per position in the 4 x 4 block) of 18 x 18 blocks (16 + ghost
-//     ring), so every halo read is a unit-stride ds_read_b32 across the wave;
-//   * a pass = read 20 halo cells, one forward and one backward Gauss-Seidel
-//     sweep of the block in registers (v_min3/v_max), publish, vote; passes
-//     repeat inside LDS until the tile stops changing (information crosses a
-//     tile without touching HBM);
-//   * on exit the tile is written back once, and the up-to-8 neighbour tiles
-//     whose shared edge changed are appended to the next round's worklist
-//     (stamp-deduplicated, no clearing pass).
-// HBM traffic per tile visit is the algorithmic 12 B/cell (Z in, W in, W out)
-// + the 260-cell halo ring; unchanged tiles skip the write.
+// The visit (gfx950):
+//   * the interior of the raster is cut into 62 x 62 cell tiles; a tile is
+//     relaxed inside its 64 x 64 window (tile + one-cell halo ring, the ring
+//     pinned for the duration of the visit);
+//   * ONE WAVE relaxes one tile: lane c holds column c of the window, 64 rows
+//     of Z and 64 of W, in VGPRs (a wave-level load moves one 256-byte row
+//     piece; all 128 are in flight together).  A north->south scan walks the
+//     rows in registers: w[r] <- med3(z[r], w[r], min3 of row r-1 at lanes
+//     c-1,c,c+1) -- two v_mov_dpp wave shifts, v_min3, v_med3, v_cmp: 5 VALU per
+//     row, no memory.  South->north likewise.  The window is then transposed
+//     through a 64 x 65 LDS buffer (conflict-free both ways) so that lane = row,
+//     and the same code scans west->east and east->west.  The four scans cover
+//     all eight neighbours; a Jacobi check (one full T step, a third of the
+//     cost) decides whether another round of scans is needed;
+//   * the wave writes the tile back once (62 rows x 248 B) and wakes only those
+//     of its 8 neighbour tiles that one of its changed edge cells can still
+//     lower (compared against the halo it holds in registers).
+//
+// The schedule:
+//   * every tile has a fixed owner workgroup (tile t -> workgroup t % G, slot
+//     t / G; one state word per tile, [owner][slot]), so there are no queues and
+//     no contended counters -- a single hot atomic costs ~12 ns per arrival and
+//     was measured to dominate everything else here;
+//   * asynchronous driver (the work horse): one persistent launch; a workgroup
+//     keeps relaxing whichever of its queued tiles carries the lowest key (the
+//     lowest elevation a neighbour offered it: flood order, which keeps the
+//     visits per tile low); waking a neighbour is one compare-and-swap on its
+//     state word;
+//   * round-synchronous driver: one launch per round, state word = stamp of the
+//     round the tile is due in, waking is a plain store.  Used behind the
+//     asynchronous launch to certify (or finish) the fixed point, and on its own
+//     with HDEM_FILL_SYNC_ONLY.
+// HBM traffic per tile visit: Z in + W in (2 x 64 x 256 B) + W out when changed;
+// the algorithmic figure is 12 B per tile cell.
 #include "hdem_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
-constexpr int FT = 64;             // tile edge (cells)
-constexpr int NB = FT / 4;         // 4x4 blocks per tile edge
-constexpr int GS = NB + 2;         // block grid incl. ghost ring
-constexpr int PLANE = GS * GS;
-constexpr int NT = 256;
-constexpr int PASS_MAX = 64;       // in-LDS passes before the tile re-queues
+constexpr int FT = 62;             // tile edge (cells)
+constexpr int WN = 64;             // window edge = tile + halo ring = wave width
+constexpr int TS = WN + 1;         // LDS row stride (floats): conflict-free transposes
+constexpr int NT = 64;             // one wave per workgroup
+constexpr int ITER_MAX = 8;        // 4-scan iterations before the tile re-queues
+constexpr int INIT_NT = 256;
+constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
+constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
+constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
+#ifdef HDEM_VISIT_PROF
+constexpr int STAT_WORDS = 12;
+#else
+constexpr int STAT_WORDS = 6;      // per workgroup: visits, iterations, unchanged, re-queued,
+                                   // busy ticks, idle ticks (100 MHz, async driver)
+#endif
+enum { ST_IDLE = 0, ST_QUEUED = 1, ST_RUNNING = 2, ST_DIRTY = 3, ST_ROUND0 = 16 };
 
 struct fill_ws {
-    int *list[2];
-    int *flag;          // last round stamp for which the tile was queued
-    int *tile_pinned;   // init only
-    int *counts;        // counts[r] = entries in the list consumed by round r
-    int ntiles, tiles_x, tiles_y, max_rounds;
+    int *tile_key;      // INIT: lowest pinned elevation next to the tile
+    int *state;         // [G][S] async: ST_*; round driver: stamp of the round the tile is due in
+    int *prio;          // [G][S] lowest key offered while queued
+    int *pend;          // sharded count of non-idle tiles (async)
+    int *any;           // any[r] != 0: round r has work
+    int *error;
+    unsigned long long *stats;   // [G][STAT_WORDS], written only by the owner
+    int ntiles, tiles_x, tiles_y, max_rounds, G, S;
 };
 
-__device__ __forceinline__ void enqueue(int t, int stamp, int *flag, int *list_next,
-                                        int *count_next)
+// lane i <- lane i-1 / lane i+1 across the whole wave (gfx9 wave_shr / wave_shl).
+// bound_ctrl: the lane without a source (0 resp. 63) reads 0 -- harmless where
+// those two lanes are the pinned window ring and ignore their candidate.
+__device__ __forceinline__ float lane_prev(float v)
 {
-    if (atomicExch(&flag[t], stamp) != stamp) {
-        int i = atomicAdd(count_next, 1);
-        list_next[i] = t;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_next(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// acc |= lanes where a != b.  Written as asm so that the compare result is
+// folded into ONE scalar pair at once (left to itself hipcc keeps 62 compare
+// masks per scan alive and spills ~550 SGPRs).
+__device__ __forceinline__ void or_changed(unsigned long long &acc, float a, float b)
+{
+    asm volatile("v_cmp_neq_f32 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc"
+                 : "+s"(acc) : "v"(a), "v"(b) : "vcc", "scc");   // s_or_b64 writes SCC
+}
+// acc |= lanes where a < b
+__device__ __forceinline__ void or_less(unsigned long long &acc, float a, float b)
+{
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc"
+                 : "+s"(acc) : "v"(a), "v"(b) : "vcc", "scc");
+}
+
+struct scan_masks {                 // wave-uniform (SGPR) lane masks of changed cells
+    unsigned long long first, last, all;
+};
+
+// One directional scan over the 64 lines held in registers.  Line i takes the
+// three neighbours on the previously visited line; lines 0 and 63 and lanes 0
+// and 63 are the pinned ring (z == w there, so med3 returns w).  Needs
+// z[i] <= w[i], which every valid upper bound of W* satisfies.
+template <bool HAS_EPS, bool FWD>
+__device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN], float eps,
+                                           scan_masks &m)
+{
+    float prev = w[FWD ? 0 : WN - 1];
+#pragma unroll
+    for (int k = 1; k <= WN - 2; ++k) {
+        const int i = FWD ? k : WN - 1 - k;
+        float c = fminf(fminf(prev, lane_prev(prev)), lane_next(prev));
+        if (HAS_EPS) c = c + eps;
+        const float n = __builtin_amdgcn_fmed3f(z[i], w[i], c);
+        if (i == 1) or_changed(m.first, n, w[i]);
+        else if (i == WN - 2) or_changed(m.last, n, w[i]);
+        else or_changed(m.all, n, w[i]);
+        w[i] = n;
+        prev = n;
     }
 }
 
-__device__ __forceinline__ float ld_w(const float *w, int H, int W, int y, int x)
-{   // halo read: outside the raster and nodata act as +inf walls
-    if (y < 0 || y >= H || x < 0 || x >= W) return HDEM_INF;
-    float v = w[(size_t)y * W + x];
-    return v != v ? HDEM_INF : v;
+// One full application of T in the column layout (Jacobi order): row r takes
+// the 3x3 minimum around each cell.  Costs a third of a 4-scan iteration and
+// is the convergence test: if it lowers nothing, the window is at its fixed
+// point for the current halo.
+template <bool HAS_EPS>
+__device__ __forceinline__ void check_rows(const float (&z)[WN], float (&w)[WN], float eps,
+                                           scan_masks &m)
+{
+    // h[r] = min of row r at lanes c-1, c, c+1 (self included: harmless, med3 clamps at w)
+    float h_prev = fminf(fminf(w[0], lane_prev(w[0])), lane_next(w[0]));
+    float h_cur = fminf(fminf(w[1], lane_prev(w[1])), lane_next(w[1]));
+#pragma unroll
+    for (int r = 1; r <= WN - 2; ++r) {
+        const float h_next = fminf(fminf(w[r + 1], lane_prev(w[r + 1])), lane_next(w[r + 1]));
+        float c = fminf(fminf(h_prev, h_cur), h_next);
+        if (HAS_EPS) c = c + eps;
+        const float n = __builtin_amdgcn_fmed3f(z[r], w[r], c);
+        if (r == 1) or_changed(m.first, n, w[r]);
+        else if (r == WN - 2) or_changed(m.last, n, w[r]);
+        else or_changed(m.all, n, w[r]);
+        w[r] = n;
+        h_prev = h_cur;
+        h_cur = h_next;
+    }
 }
 
-__device__ __forceinline__ float min9(float a, float b, float c, float d, float e,
-                                      float f, float g, float h)
+// registers (lane = column, index = row)  <->  registers (lane = row, index = column)
+__device__ __forceinline__ void transpose(float (&v)[WN], float *T, int lane)
 {
-    float m = fminf(fminf(a, b), c);
-    m = fminf(fminf(m, d), e);
-    m = fminf(fminf(m, f), g);
-    return fminf(m, h);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) T[i * TS + lane] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WN; ++i) v[i] = T[lane * TS + i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// order-preserving float -> int key (so that atomicMin on ints orders floats)
+__device__ __forceinline__ int float_key(float f)
+{
+    int i = __builtin_bit_cast(int, f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+
+#ifdef HDEM_VISIT_PROF
+#define PROF_MARK(k) do { long long now_ = wall_clock64(); out.ticks[k] += now_ - tprof_; tprof_ = now_; } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
+
+struct visit_result {
+#ifdef HDEM_VISIT_PROF
+    long long ticks[6];   // load, first check, zt transpose, iterations, store, wake tests
+#endif
+    bool changed;      // some interior cell was lowered (the tile was written back)
+    bool more;         // still changing at the iteration cap: visit again
+    unsigned dirs;     // bit k set: neighbour k (NW,N,NE,W,E,SW,S,SE) can use the new edge
+    int key;           // PER LANE: lane k < 8 holds the lowest value now offered to
+                       // neighbour k (priority key); lane 8 the lowest of the eight
+    int iters;
+};
+
+// Relax one tile to its fixed point for the current halo.  Whole wave, wave-uniform
+// result.  T: the wave's 64 x 65 float LDS buffer.
+// COHERENT (asynchronous driver): W is read and written with agent-scope (sc1)
+// accesses -- loads bypass L1, stores write through -- so that a tile handed from
+// one workgroup to another inside the launch needs no cache-wide fence
+// (MI355X_MICROARCH.md, "Valid forms").  The round driver uses plain accesses.
+template <bool HAS_EPS, bool COHERENT>
+__device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
+                                                   int H, int W, float eps, int ty, int tx,
+                                                   float *T)
+{
+    const int lane = threadIdx.x;
+    const int y0 = ty * FT, x0 = tx * FT;              // window origin (= halo row/col)
+    const int x = x0 + lane;
+
+    // ---- load the window: lane = column -------------------------------------
+    // Addresses are clamped into the raster instead of predicated, so that all 128
+    // row loads of the lane are in flight together.
+    float z[WN], w[WN];
+    const int xc = min(x, W - 1);
+#pragma unroll
+    for (int r = 0; r < WN; ++r) {
+        const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+        z[r] = zg[o];
+        if (COHERENT)
+            w[r] = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int *>(wg + o),
+                                                               __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+        else
+            w[r] = wg[o];
+    }
+#pragma unroll
+    for (int r = 0; r < WN; ++r) {
+        const int y = y0 + r;
+        const bool inside = x < W && y < H;
+        float zc = inside ? z[r] : HDEM_INF, wc = inside ? w[r] : HDEM_INF;
+        const bool nan = zc != zc;
+        if (wc != wc) wc = HDEM_INF;
+        // window ring, raster ring and everything outside: pinned for this visit
+        const bool pinned = r == 0 || r == WN - 1 || lane == 0 || lane == WN - 1 ||
+                            y == 0 || y >= H - 1 || x == 0 || x >= W - 1;
+        z[r] = nan ? HDEM_INF : (pinned ? wc : zc);
+        w[r] = wc;
+    }
+
+    visit_result out;
+#ifdef HDEM_VISIT_PROF
+    for (int k = 0; k < 6; ++k) out.ticks[k] = 0;
+    long long tprof_ = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PROF_MARK(0);
+#endif
+    out.dirs = 0;
+    out.iters = 0;
+    out.key = KEY_NONE;
+    scan_masks V = {0, 0, 0}, Hm = {0, 0, 0};          // cumulative over the visit
+    check_rows<HAS_EPS>(z, w, eps, V);
+    V.all |= V.first | V.last;
+    bool more = V.all != 0;
+    out.changed = more;
+    PROF_MARK(1);
+    if (more) {
+        float zt[WN];
+#pragma unroll
+        for (int r = 0; r < WN; ++r) zt[r] = z[r];
+        transpose(zt, T, lane);                        // zt: lane = row
+        PROF_MARK(2);
+        for (; out.iters < ITER_MAX && more; ++out.iters) {
+            scan_masks v = {0, 0, 0}, h = {0, 0, 0};
+            scan_lines<HAS_EPS, true>(z, w, eps, v);   // north -> south
+            scan_lines<HAS_EPS, false>(z, w, eps, v);  // south -> north
+            transpose(w, T, lane);
+            scan_lines<HAS_EPS, true>(zt, w, eps, h);  // west -> east
+            scan_lines<HAS_EPS, false>(zt, w, eps, h); // east -> west
+            // back to lane = column
+#pragma unroll
+            for (int i = 0; i < WN; ++i) T[lane * TS + i] = w[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < WN; ++i) w[i] = T[i * TS + lane];
+            __syncthreads();
+            scan_masks c = {0, 0, 0};
+            check_rows<HAS_EPS>(z, w, eps, c);         // convergence test (and one more T step)
+            c.all |= c.first | c.last;
+            v.all |= v.first | v.last | c.all;         // `all` skips lines 1 and 62 in the scans
+            v.first |= c.first;
+            v.last |= c.last;
+            h.all |= h.first | h.last;
+            V.first |= v.first; V.last |= v.last; V.all |= v.all;
+            Hm.first |= h.first; Hm.last |= h.last; Hm.all |= h.all;
+            more = c.all != 0;
+        }
+
+        PROF_MARK(3);
+        // ---- write back --------------------------------------------------------
+        if (lane >= 1 && lane <= FT && x <= W - 2) {
+#pragma unroll
+            for (int r = 1; r <= FT; ++r) {
+                const int y = y0 + r;
+                // a nodata cell was loaded as the wall z = w = +inf; it goes back as NaN
+                // (an interior cell that no path reaches keeps w = +inf but a finite z)
+                if (y <= H - 2) {
+                    const float val = z[r] == HDEM_INF ? __builtin_nanf("") : w[r];
+                    if (COHERENT)
+                        __hip_atomic_store(reinterpret_cast<int *>(wg + (size_t)y * W + x),
+                                           __builtin_bit_cast(int, val), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        wg[(size_t)y * W + x] = val;
+                }
+            }
+        }
+
+#ifdef HDEM_VISIT_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PROF_MARK(4);
+        // ---- which neighbours can use the new edge, and how low it is -------------
+        // A neighbour cell n next to my edge cell a can only drop if w[a] + eps < w[n];
+        // w[n] is the halo value held since the load (stale means higher: the test
+        // errs towards waking).  Rows first: lane c tests halo cell (0, c) / (63, c)
+        // against my row 1 / 62 at lanes c-1, c, c+1.
+        const unsigned long long b1 = 1ull << 1, bl = 1ull << FT, mid = ((1ull << FT) - 1) << 1;
+        const bool inner = lane >= 1 && lane <= FT;
+        const float e1 = inner ? w[1] : HDEM_INF, e62 = inner ? w[FT] : HDEM_INF;
+        // lanes 0/63 of the shifted copies read 0 under bound_ctrl: rebuild them as +inf
+        const float p1 = lane == 0 ? HDEM_INF : lane_prev(e1);
+        const float n1 = lane == WN - 1 ? HDEM_INF : lane_next(e1);
+        const float p62 = lane == 0 ? HDEM_INF : lane_prev(e62);
+        const float n62 = lane == WN - 1 ? HDEM_INF : lane_next(e62);
+        float cn = fminf(fminf(e1, p1), n1), cs = fminf(fminf(e62, p62), n62);
+        if (HAS_EPS) { cn += eps; cs += eps; }
+        unsigned long long north = 0, south = 0;
+        or_less(north, cn, w[0]);
+        or_less(south, cs, w[WN - 1]);
+        const bool row1_moved = V.first != 0 || (Hm.all & b1);
+        const bool row62_moved = V.last != 0 || (Hm.all & bl);
+        if (row1_moved) {
+            if (north & mid) out.dirs |= 1u << 1;                                  // N
+            if (north & 1ull) out.dirs |= 1u << 0;                                 // NW
+            if (north & (1ull << (WN - 1))) out.dirs |= 1u << 2;                   // NE
+        }
+        if (row62_moved) {
+            if (south & mid) out.dirs |= 1u << 6;                                  // S
+            if (south & 1ull) out.dirs |= 1u << 5;                                 // SW
+            if (south & (1ull << (WN - 1))) out.dirs |= 1u << 7;                   // SE
+        }
+        // Columns: lane 0 holds the west halo column, lane 1 my column 1 (lane 63 / 62
+        // for the east); row r of the halo is tested against rows r-1, r, r+1.
+        const bool col1_moved = (V.all & b1) || Hm.first != 0;
+        const bool col62_moved = (V.all & bl) || Hm.last != 0;
+        if (col1_moved || col62_moved) {
+            unsigned long long side = 0;   // bit 0: west halo can drop, bit 63: east halo
+            // q[r] = my edge column next to this lane's halo column (lane 0 <- lane 1,
+            // lane 63 <- lane 62); the other lanes compute values that are masked off
+            float q_prev = HDEM_INF;
+            float q_cur = lane == 0 ? lane_next(w[1]) : lane_prev(w[1]);
+#pragma unroll
+            for (int r = 1; r <= FT; ++r) {
+                float q_next = HDEM_INF;
+                if (r < FT) q_next = lane == 0 ? lane_next(w[r + 1]) : lane_prev(w[r + 1]);
+                float c = fminf(fminf(q_prev, q_cur), q_next);
+                if (HAS_EPS) c = c + eps;
+                or_less(side, c, w[r]);
+                q_prev = q_cur;
+                q_cur = q_next;
+            }
+            if (col1_moved && (side & 1ull)) out.dirs |= 1u << 3;                  // W
+            if (col62_moved && (side & (1ull << (WN - 1)))) out.dirs |= 1u << 4;   // E
+        }
+        float colmin = HDEM_INF;
+#pragma unroll
+        for (int r = 1; r <= FT; ++r) colmin = fminf(colmin, w[r]);
+        const float k_n = wave_min(e1), k_s = wave_min(e62);
+        const float k_w = __shfl(colmin, 1), k_e = __shfl(colmin, FT);
+        const float k_nw = __shfl(w[1], 1), k_ne = __shfl(w[1], FT);
+        const float k_sw = __shfl(w[FT], 1), k_se = __shfl(w[FT], FT);
+        const float k_all = fminf(fminf(k_n, k_s), fminf(k_w, k_e));   // corners lie on the edges
+        const float mine = lane == 0 ? k_nw : lane == 1 ? k_n : lane == 2 ? k_ne
+                         : lane == 3 ? k_w : lane == 4 ? k_e : lane == 5 ? k_sw
+                         : lane == 6 ? k_s : lane == 7 ? k_se : k_all;
+        out.key = float_key(mine);
+        PROF_MARK(5);
+    }
+    out.more = more;
+    return out;
+}
+
+__device__ __forceinline__ int neighbour_tile(int k, int ty, int tx, int tiles_x, int tiles_y)
+{   // k: NW,N,NE,W,E,SW,S,SE ; -1 when outside the tile grid
+    const int dy = k < 3 ? -1 : (k < 5 ? 0 : 1);
+    const int dx = (k == 0 || k == 3 || k == 5) ? -1 : ((k == 1 || k == 6) ? 0 : 1);
+    const int ny = ty + dy, nx = tx + dx;
+    return (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) ? ny * tiles_x + nx : -1;
+}
+
+__device__ __forceinline__ void add_stats(unsigned long long *stats, int b, bool changed,
+                                          bool more, int iters)
+{   // one writer per workgroup: plain read-modify-write, no atomics
+    unsigned long long *s = stats + (size_t)b * STAT_WORDS;
+    s[0] += 1;
+    s[1] += (unsigned long long)iters;
+    s[2] += changed ? 0 : 1;
+    s[3] += more ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// Round-synchronous driver: one launch per round.  A tile is due in round r when
+// its state word holds stamp r; waking a tile for the next round is a plain store
+// of stamp r+1 (every writer stores the same value), and *any_next is set the
+// same way -- no atomics.  Used to certify / finish the fixed point behind the
+// asynchronous launch, and alone with HDEM_FILL_SYNC_ONLY.
+// ---------------------------------------------------------------------------
+template <bool HAS_EPS>
+__global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restrict__ zg,
+                                                          float *wg, int H, int W, float eps,
+                                                          int tiles_x, int tiles_y, int ntiles,
+                                                          int S, int *state, int stamp,
+                                                          int *any_next,
+                                                          unsigned long long *stats)
+{
+    __shared__ float T[WN * TS];
+    const int lane = threadIdx.x;
+    const int G = gridDim.x, b = blockIdx.x;
+    int *my_state = state + (size_t)b * S;
+    for (int base = 0; base < S; base += NT) {
+        const int slot_l = base + lane;
+        const bool due_l = slot_l < S && slot_l * G + b < ntiles && my_state[slot_l] == stamp;
+        unsigned long long due = __ballot(due_l);
+        while (due) {
+            const int slot = base + __builtin_ctzll(due);
+            due &= due - 1;
+            const int t = slot * G + b;
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const visit_result v = tile_visit<HAS_EPS, false>(zg, wg, H, W, eps, ty, tx, T);
+            if (lane < 8 && ((v.dirs >> lane) & 1u)) {
+                const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
+                if (t2 >= 0) {
+                    state[(size_t)(t2 % G) * S + t2 / G] = stamp + 1;
+                    *any_next = 1;
+                }
+            }
+            if (lane == 8) {
+                if (v.more) {
+                    my_state[slot] = stamp + 1;
+                    *any_next = 1;
+                }
+                add_stats(stats, b, v.changed, v.more, v.iters);
+#ifdef HDEM_VISIT_PROF
+                for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
+#endif
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Asynchronous driver.  state: IDLE -> QUEUED (by a neighbour) -> RUNNING (by the
+// owner) -> IDLE; RUNNING -> DIRTY when a neighbour's edge moves during the
+// visit; a DIRTY tile goes back to QUEUED when its visit ends.
+//   pend[]: tiles in a non-IDLE state, sharded over 64 cache lines.  A workgroup
+//          leaves when it has nothing queued and reads an all-zero sum twice;
+//          leaving early is harmless -- the round-synchronous pass behind this
+//          kernel finishes whatever is left and is what certifies the result.
+//   memory: the writer drains its stores, releases at agent scope, then wakes;
+//          the owner marks RUNNING, acquires at agent scope, then loads
+//          (cdna_hip_programming.md, Guideline 16).
+//   exit:  every wait is bounded by a wall-clock budget; on expiry the kernel
+//          sets *error and drains.
+// The scheduler half is kept out of line: inlined around the visit it pushes the
+// visit body over 256 VGPRs; as calls made while no window is live it is free.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int ld_relaxed(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void wake_async(int t2, int key, int G, int S, int *state,
+                                           int *prio, int *pend)
+{
+    const int owner = t2 % G, idx = owner * S + t2 / G;
+    atomicMin(&prio[idx], key);
+    for (int tries = 0; tries < 8; ++tries) {
+        const int s = atomicCAS(&state[idx], ST_IDLE, ST_QUEUED);
+        if (s == ST_IDLE) {
+            atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
+            return;
+        }
+        if (s == ST_QUEUED || s == ST_DIRTY) return;
+        const int s2 = atomicCAS(&state[idx], ST_RUNNING, ST_DIRTY);
+        if (s2 != ST_IDLE) return;                      // RUNNING->DIRTY done, or already marked
+    }
+}
+
+// Returns the tile to relax next, -1 to stop (drained or out of budget).
+__device__ __attribute__((noinline)) int async_pick(int b, int G, int S, int ntiles, int *state,
+                                                    int *prio, const int *pend, int *error,
+                                                    long long t_begin, long long budget_ticks)
+{
+    const int lane = threadIdx.x;
+    int *my_state = state + (size_t)b * S, *my_prio = prio + (size_t)b * S;
+    int zero_reads = 0;
+    for (;;) {
+        // the queued slot with the lowest key
+        long long best = 0x7fffffffffffffffll;
+        for (int base = 0; base < S; base += NT) {
+            const int slot = base + lane;
+            long long cand = 0x7fffffffffffffffll;
+            if (slot < S && slot * G + b < ntiles && ld_relaxed(&my_state[slot]) == ST_QUEUED)
+                cand = ((long long)ld_relaxed(&my_prio[slot]) << 32) | (unsigned)slot;
+            best = cand < best ? cand : best;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const long long other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        if (best != 0x7fffffffffffffffll) {
+            const int slot = (int)(best & 0xffffffffll);
+            if (lane == 0) {
+                atomicExch(&my_prio[slot], KEY_NONE);
+                atomicExch(&my_state[slot], ST_RUNNING);
+            }
+            return slot * G + b;
+        }
+        // nothing queued here: leave once the whole raster looks drained
+        int p = ld_relaxed(&pend[lane * PEND_STRIDE]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o);
+        if (p <= 0) { if (++zero_reads >= 2) return -1; } else zero_reads = 0;
+        if (wall_clock64() - t_begin > budget_ticks) {
+            if (lane == 0) atomicExch(error, 1);
+            return -1;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// Publish a finished visit: release the written tile, wake the neighbours that can
+// use the new edge, retire (or re-queue) the tile.  `key` is the per-lane key of
+// visit_result.
+__device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int S, int tiles_x,
+                                                       int tiles_y, int *state, int *prio,
+                                                       int *pend, unsigned long long *stats,
+                                                       bool changed, bool more, unsigned dirs,
+                                                       int key, int iters)
+{
+    const int lane = threadIdx.x;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x, slot = t / G;
+    int *my_state = state + (size_t)b * S, *my_prio = prio + (size_t)b * S;
+    // A tile that wakes nobody needs no release: nobody depends on seeing it before
+    // the launch ends (its edge cannot lower any neighbour cell).
+    if (changed && dirs) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
+        if (lane < 8 && ((dirs >> lane) & 1u)) {
+            const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
+            if (t2 >= 0) wake_async(t2, key, G, S, state, prio, pend);
+        }
+    }
+    if (lane == 8) {
+        if (more) atomicMin(&my_prio[slot], key);
+        const int target = more ? ST_QUEUED : ST_IDLE;
+        const int old = atomicCAS(&my_state[slot], ST_RUNNING, target);
+        if (old == ST_DIRTY) atomicExch(&my_state[slot], ST_QUEUED);
+        else if (target == ST_IDLE) atomicAdd(pend + (b % PEND_SHARDS) * PEND_STRIDE, -1);
+        add_stats(stats, b, changed, more, iters);
+    }
 }
 
 template <bool HAS_EPS>
-__global__ __launch_bounds__(NT) void fill_tile_kernel(const float *__restrict__ z,
-                                                      float *w, int H, int W, float eps,
-                                                      int tiles_x, int tiles_y,
-                                                      const int *__restrict__ list_cur,
-                                                      const int *__restrict__ count_cur,
-                                                      int *list_next, int *count_next,
-                                                      int *flag, int stamp)
+__global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restrict__ zg,
+                                                          float *wg, int H, int W, float eps,
+                                                          int tiles_x, int tiles_y, int ntiles,
+                                                          int S, int *state, int *prio,
+                                                          int *pend, int *error,
+                                                          unsigned long long *stats,
+                                                          long long budget_ticks)
 {
-    __shared__ float P[16 * PLANE];
-    __shared__ int edge_bits;
-
-    const int tid = threadIdx.x;
-    const int bx = tid & (NB - 1), by = tid >> 4;
-    const int n_cur = *count_cur;
-
-    for (int li = blockIdx.x; li < n_cur; li += gridDim.x) {
-        const int t = list_cur[li];
+    __shared__ float T[WN * TS];
+    const int G = gridDim.x, b = blockIdx.x;
+    const long long t_begin = wall_clock64();
+    long long t_mark = t_begin, busy = 0, idle = 0;
+    for (;;) {
+        // readfirstlane: the tile index is wave-uniform; say so, or every row address
+        // of the visit is computed (and kept) per lane
+        const int t = __builtin_amdgcn_readfirstlane(
+            async_pick(b, G, S, ntiles, state, prio, pend, error, t_begin, budget_ticks));
+        long long now = wall_clock64();
+        idle += now - t_mark;
+        t_mark = now;
+        if (t < 0) break;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const int y0 = ty * FT, x0 = tx * FT;
-        const int gy = y0 + 4 * by, gx = x0 + 4 * bx;
-        if (tid == 0) edge_bits = 0;
-
-        // ---- load the lane's 4x4 block of Z and W -------------------------
-        float zz[4][4], e[6][6];
-        unsigned nanmask = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = gy + r;
-            hdem_f4 vz = {HDEM_INF, HDEM_INF, HDEM_INF, HDEM_INF}, vw = vz;
-            if (y < H) {
-                const size_t o = (size_t)y * W + gx;
-                if (gx + 4 <= W) {
-                    vz = hdem_ld4u(z + o);
-                    vw = hdem_ld4u(w + o);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (gx + c < W) { vz[c] = z[o + c]; vw[c] = w[o + c]; }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int x = gx + c;
-                float zc = vz[c], wc = vw[c];
-                const bool nan = zc != zc;
-                const bool ring = y == 0 || y == H - 1 || x == 0 || x == W - 1;
-                if (nan) nanmask |= 1u << (r * 4 + c);
-                if (wc != wc) wc = HDEM_INF;
-                // pinned cells: the update max(zz, min(w, .)) leaves w alone
-                zz[r][c] = nan ? HDEM_INF : (ring ? wc : zc);
-                e[r + 1][c + 1] = wc;
-            }
+        const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T);
+#ifdef HDEM_VISIT_PROF
+        const long long t_v = wall_clock64();
+#endif
+        async_finish(t, b, G, S, tiles_x, tiles_y, state, prio, pend, stats, v.changed, v.more,
+                     v.dirs, v.key, v.iters);
+        now = wall_clock64();
+#ifdef HDEM_VISIT_PROF
+        if (threadIdx.x == 8) {
+            for (int k = 1; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
+            stats[(size_t)b * STAT_WORDS + 6] += (unsigned long long)(now - t_v);   // finish
         }
-
-        // ---- publish the block, fetch the tile's halo ring ----------------
-        const int me = (by + 1) * GS + bx + 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) P[(r * 4 + c) * PLANE + me] = e[r + 1][c + 1];
-        {
-            const int i = tid & 63, q = i >> 2, s = i & 3;
-            if (tid < 64)        // row above the tile -> bottom row of ghost blocks
-                P[(12 + s) * PLANE + 0 * GS + q + 1] = ld_w(w, H, W, y0 - 1, x0 + i);
-            else if (tid < 128)  // row below
-                P[(0 + s) * PLANE + (NB + 1) * GS + q + 1] = ld_w(w, H, W, y0 + FT, x0 + i);
-            else if (tid < 192)  // column left
-                P[(s * 4 + 3) * PLANE + (q + 1) * GS + 0] = ld_w(w, H, W, y0 + i, x0 - 1);
-            else                 // column right
-                P[(s * 4 + 0) * PLANE + (q + 1) * GS + NB + 1] = ld_w(w, H, W, y0 + i, x0 + FT);
-            if (tid == 0) P[15 * PLANE + 0] = ld_w(w, H, W, y0 - 1, x0 - 1);
-            if (tid == 1) P[12 * PLANE + NB + 1] = ld_w(w, H, W, y0 - 1, x0 + FT);
-            if (tid == 2) P[3 * PLANE + (NB + 1) * GS] = ld_w(w, H, W, y0 + FT, x0 - 1);
-            if (tid == 3) P[0 * PLANE + (NB + 1) * GS + NB + 1] = ld_w(w, H, W, y0 + FT, x0 + FT);
-        }
-        __syncthreads();
-
-        // ---- in-LDS passes -------------------------------------------------
-        unsigned chmask = 0;
-        int pass = 0;
-        bool more = true;
-        for (; pass < PASS_MAX && more; ++pass) {
-            // 20 halo cells: rows above/below (with corners), columns left/right
-            e[0][0] = P[15 * PLANE + me - GS - 1];
-            e[0][5] = P[12 * PLANE + me - GS + 1];
-            e[5][0] = P[3 * PLANE + me + GS - 1];
-            e[5][5] = P[0 * PLANE + me + GS + 1];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                e[0][c + 1] = P[(12 + c) * PLANE + me - GS];
-                e[5][c + 1] = P[(0 + c) * PLANE + me + GS];
-                e[c + 1][0] = P[(c * 4 + 3) * PLANE + me - 1];
-                e[c + 1][5] = P[(c * 4 + 0) * PLANE + me + 1];
-            }
-            float old[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) old[r][c] = e[r + 1][c + 1];
-            // forward then backward Gauss-Seidel sweep of the block
-#pragma unroll
-            for (int dir = 0; dir < 2; ++dir)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) {
-                        const int r = dir ? 4 - rr : rr + 1, c = dir ? 4 - cc : cc + 1;
-                        float m = min9(e[r - 1][c - 1], e[r - 1][c], e[r - 1][c + 1],
-                                       e[r][c - 1], e[r][c + 1], e[r + 1][c - 1],
-                                       e[r + 1][c], e[r + 1][c + 1]);
-                        if (HAS_EPS) m = m + eps;
-                        e[r][c] = fmaxf(zz[r - 1][c - 1], fminf(e[r][c], m));
-                    }
-            unsigned bits = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (e[r + 1][c + 1] != old[r][c]) {
-                        bits |= 1u << (r * 4 + c);
-                        P[(r * 4 + c) * PLANE + me] = e[r + 1][c + 1];
-                    }
-            chmask |= bits;
-            more = __syncthreads_or(bits != 0) != 0;
-        }
-        const bool converged = !more;
-
-        // ---- write back, wake the neighbours whose edge moved --------------
-        if (__syncthreads_or(chmask != 0)) {
-            if (chmask) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = gy + r;
-                    if (y >= H || !((chmask >> (4 * r)) & 0xFu)) continue;
-                    const size_t o = (size_t)y * W + gx;
-                    hdem_f4 v;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        v[c] = (nanmask >> (r * 4 + c)) & 1u ? __builtin_nanf("") : e[r + 1][c + 1];
-                    if (gx + 4 <= W) {
-                        hdem_st4u(w + o, v);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (gx + c < W) w[o + c] = v[c];
-                    }
-                }
-                unsigned d = 0;
-                if (by == 0 && (chmask & 0x000Fu)) d |= 1u << 1;            // N
-                if (by == NB - 1 && (chmask & 0xF000u)) d |= 1u << 6;       // S
-                if (bx == 0 && (chmask & 0x1111u)) d |= 1u << 3;            // W
-                if (bx == NB - 1 && (chmask & 0x8888u)) d |= 1u << 4;       // E
-                if (by == 0 && bx == 0 && (chmask & 0x0001u)) d |= 1u << 0;             // NW
-                if (by == 0 && bx == NB - 1 && (chmask & 0x0008u)) d |= 1u << 2;        // NE
-                if (by == NB - 1 && bx == 0 && (chmask & 0x1000u)) d |= 1u << 5;        // SW
-                if (by == NB - 1 && bx == NB - 1 && (chmask & 0x8000u)) d |= 1u << 7;   // SE
-                if (d) atomicOr(&edge_bits, (int)d);
-            }
-            __syncthreads();
-            if (tid < 8 && ((edge_bits >> tid) & 1)) {
-                const int dy = tid < 3 ? -1 : (tid < 5 ? 0 : 1);
-                const int dx = (tid == 0 || tid == 3 || tid == 5) ? -1
-                               : ((tid == 1 || tid == 6) ? 0 : 1);
-                const int ny = ty + dy, nx = tx + dx;
-                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x)
-                    enqueue(ny * tiles_x + nx, stamp, flag, list_next, count_next);
-            }
-        }
-        if (!converged && tid == 8) enqueue(t, stamp, flag, list_next, count_next);
-        __syncthreads();   // LDS is reused by the next tile of this workgroup
+#endif
+        busy += now - t_mark;
+        t_mark = now;
+    }
+    if (threadIdx.x == 0) {
+        stats[(size_t)b * STAT_WORDS + 4] += (unsigned long long)busy;
+        stats[(size_t)b * STAT_WORDS + 5] += (unsigned long long)idle;
     }
 }
 
 // W0: pinned cells <- Z (ring, nodata, neighbours of nodata), the rest +inf.
-// One lane per cell; the 3x3 nodata probe is served by L1/L2.
-__global__ __launch_bounds__(NT) void fill_init_kernel(const float *__restrict__ z,
+// One lane per cell; the 3x3 nodata probe is served by L1/L2.  tile_key[t]
+// receives the lowest pinned elevation next to tile t (KEY_NONE: none).
+__global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restrict__ z,
                                                       float *__restrict__ w, int H, int W,
-                                                      int tiles_x, int *tile_pinned,
+                                                      int tiles_x, int *tile_key,
                                                       int ghost_top, int ghost_bottom)
 {
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
     if (i >= (size_t)H * W) return;
     const int y = (int)(i / W), x = (int)(i % W);
     const float zc = z[i];
@@ -271,55 +642,70 @@ __global__ __launch_bounds__(NT) void fill_init_kernel(const float *__restrict__
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const float zn = z[(size_t)(y + dy) * W + (x + dx)];
-                pin |= zn != zn;   // (a nodata cell in a ghost row pins too: it is nodata for its owner as well)
+                pin |= zn != zn;   // a nodata cell in a ghost row is nodata for its owner too
             }
     }
     w[i] = pin ? zc : HDEM_INF;
-    if (pin && zc == zc) tile_pinned[(y / FT) * tiles_x + x / FT] = 1;
+    if (pin && zc == zc && tiles_x > 0) {
+        // the tile whose interior is nearest (ring cells belong to no interior);
+        // pinned cells are few (ring + nodata fringe), so this atomic is cold
+        const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(x - 1, 0), W - 3) / FT;
+        atomicMin(&tile_key[ty * tiles_x + tx], float_key(zc));
+    }
 }
 
-// Round-0 worklist for INIT: tiles that hold a pinned cell, and their 8
-// neighbours (a pinned cell never changes, so it cannot wake a neighbour).
-__global__ __launch_bounds__(NT) void fill_seed_kernel(const int *__restrict__ tile_pinned,
-                                                      int tiles_x, int tiles_y, int *flag,
-                                                      int *list0, int *count0, int stamp)
+// Seeds a driver.  mode < 0: INIT -- a tile starts due when it or one of its 8
+// neighbours holds a pinned cell (a pinned cell never changes, so it cannot wake a
+// neighbour later).  mode >= 0: WARM -- all tiles (0) or the tile rows next to a
+// ghost row that a halo exchange just replaced (ACT_TOP / ACT_BOTTOM bits).
+// async != 0: state QUEUED + key + pend; else state = stamp and *any0 = 1.
+__global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restrict__ tile_key,
+                                                      int tiles_x, int tiles_y, int H, int mode,
+                                                      int G, int S, int async, int *state,
+                                                      int *prio, int *pend, int stamp, int *any0)
 {
-    const int t = blockIdx.x * NT + threadIdx.x;
+    const int t = blockIdx.x * INIT_NT + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    bool act = false;
-    for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int ny = ty + dy, nx = tx + dx;
-            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x)
-                act |= tile_pinned[ny * tiles_x + nx] != 0;
-        }
-    if (act) enqueue(t, stamp, flag, list0, count0);
+    int key = KEY_NONE;
+    if (mode < 0) {
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ny = ty + dy, nx = tx + dx;
+                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x)
+                    key = min(key, tile_key[ny * tiles_x + nx]);
+            }
+    } else if (mode == 0 || ((mode & HDEM_FILL_ACT_TOP) && ty == 0) ||
+               ((mode & HDEM_FILL_ACT_BOTTOM) && ty == max(H - 3, 0) / FT)) {
+        key = 0;
+    }
+    if (key == KEY_NONE) return;
+    const int owner = t % G, idx = owner * S + t / G;
+    if (async) {
+        prio[idx] = key;
+        state[idx] = ST_QUEUED;
+        // 64 shards and one arrival per tile: ~1k arrivals per shard at 16384^2, once
+        atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
+    } else {
+        state[idx] = stamp;
+        *any0 = 1;
+    }
 }
 
-// Round-0 worklist for WARM starts: all tiles, or the tile rows next to a
-// ghost row that a halo exchange just replaced.
-__global__ __launch_bounds__(NT) void fill_seed_rows_kernel(int tiles_x, int tiles_y, int H,
-                                                           int mode, int *flag, int *list0,
-                                                           int *count0, int stamp)
+int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, fill_ws *ws)
 {
-    const int t = blockIdx.x * NT + threadIdx.x;
-    if (t >= tiles_x * tiles_y) return;
-    const int ty = t / tiles_x;
-    // a replaced ghost row can only move the row next to it: row 1 / row H-2
-    // (the ghost row itself may sit alone in the last tile row)
-    const bool act = mode == 0 || ((mode & HDEM_FILL_ACT_TOP) && ty == 1 / FT) ||
-                     ((mode & HDEM_FILL_ACT_BOTTOM) && ty == max(H - 2, 0) / FT);
-    if (act) enqueue(t, stamp, flag, list0, count0);
-}
-
-int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, fill_ws *ws)
-{
-    ws->tiles_x = (W + FT - 1) / FT;
-    ws->tiles_y = (H + FT - 1) / FT;
+    // tiles cover the interior (rows 1..H-2, cols 1..W-2); none if there is no interior
+    ws->tiles_x = W >= 3 && H >= 3 ? (W - 2 + FT - 1) / FT : 0;
+    ws->tiles_y = W >= 3 && H >= 3 ? (H - 2 + FT - 1) / FT : 0;
     ws->ntiles = ws->tiles_x * ws->tiles_y;
     ws->max_rounds = max_rounds;
-    const size_t ints = (size_t)ws->ntiles * 4 + (size_t)max_rounds + 16;
+    ws->G = std::max(1, std::min(G, ws->ntiles));
+    ws->S = std::max(1, (ws->ntiles + ws->G - 1) / ws->G);
+    const size_t n = (size_t)std::max(ws->ntiles, 1), gs = (size_t)ws->G * ws->S;
+    const size_t stat_ints = (size_t)ws->G * STAT_WORDS * 2;
+    const size_t head = 32;                                        // error + pad (128 B)
+    const size_t ints = head + stat_ints + PEND_SHARDS * PEND_STRIDE + n + 2 * gs +
+                        (size_t)max_rounds + 32;
     const size_t bytes = ints * sizeof(int);
     if (ctx->fill_ws_bytes < bytes) {
         if (ctx->fill_ws) {
@@ -331,22 +717,29 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, fill_ws *ws)
         HDEM_HIP_CHECK(hipMalloc(&ctx->fill_ws, bytes));
         ctx->fill_ws_bytes = bytes;
     }
-    if (ctx->host_counts_len < (size_t)max_rounds + 16) {
+    const size_t host_ints = std::max(stat_ints, (size_t)max_rounds + 32);
+    if (ctx->host_counts_len < host_ints) {
         if (ctx->host_counts) HDEM_HIP_CHECK(hipHostFree(ctx->host_counts));
         ctx->host_counts = nullptr;
-        HDEM_HIP_CHECK(hipHostMalloc((void **)&ctx->host_counts,
-                                     ((size_t)max_rounds + 16) * sizeof(int32_t)));
-        ctx->host_counts_len = (size_t)max_rounds + 16;
+        HDEM_HIP_CHECK(hipHostMalloc((void **)&ctx->host_counts, host_ints * sizeof(int32_t)));
+        ctx->host_counts_len = host_ints;
     }
     int *base = (int *)ctx->fill_ws;
-    ws->list[0] = base;
-    ws->list[1] = base + ws->ntiles;
-    ws->flag = base + 2 * (size_t)ws->ntiles;
-    ws->tile_pinned = base + 3 * (size_t)ws->ntiles;
-    ws->counts = base + 4 * (size_t)ws->ntiles;
-    // flags, pinned map and counters start at zero; stamps are >= 1
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->flag, 0,
-                                  (2 * (size_t)ws->ntiles + max_rounds + 16) * sizeof(int),
+    ws->error = base;
+    ws->stats = (unsigned long long *)(base + head);               // 8-byte aligned
+    ws->pend = base + head + stat_ints;
+    ws->tile_key = ws->pend + PEND_SHARDS * PEND_STRIDE;
+    ws->state = ws->tile_key + n;
+    ws->prio = ws->state + gs;
+    ws->any = ws->prio + gs;
+    // error, stats, pend = 0; tile_key / prio = "none"; state = IDLE; any = 0
+    HDEM_HIP_CHECK(hipMemsetAsync(base, 0,
+                                  (head + stat_ints + PEND_SHARDS * PEND_STRIDE) * sizeof(int),
+                                  ctx->stream));
+    HDEM_HIP_CHECK(hipMemsetAsync(ws->tile_key, 0x7f, n * sizeof(int), ctx->stream));
+    HDEM_HIP_CHECK(hipMemsetAsync(ws->state, 0, gs * sizeof(int), ctx->stream));
+    HDEM_HIP_CHECK(hipMemsetAsync(ws->prio, 0x7f, gs * sizeof(int), ctx->stream));
+    HDEM_HIP_CHECK(hipMemsetAsync(ws->any, 0, ((size_t)max_rounds + 32) * sizeof(int),
                                   ctx->stream));
     return HDEM_OK;
 }
@@ -366,70 +759,108 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (max_rounds <= 0) max_rounds = 1 << 16;
     const int K = 8;   // rounds enqueued between convergence checks
     max_rounds = (max_rounds + K - 1) / K * K;
+    const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr;
+    const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
 
     fill_ws ws;
-    if (int rc = ensure_ws(ctx, H, W, max_rounds, &ws)) return rc;
+    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * 8, &ws)) return rc;
     hipStream_t st = ctx->stream;
-    const unsigned tile_blocks = (unsigned)((ws.ntiles + NT - 1) / NT);
+    const unsigned tile_blocks = (unsigned)std::max(1, (ws.ntiles + INIT_NT - 1) / INIT_NT);
+    const bool warm = (flags & HDEM_FILL_WARM) != 0;
+    const int mode = warm ? (flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM)) : -1;
 
-    if (!(flags & HDEM_FILL_WARM)) {
-        {
-            hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
-            const size_t n = (size_t)H * W;
-            hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT),
-                               0, st, z, w, H, W, ws.tiles_x, ws.tile_pinned,
-                               flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);
-        }
-        hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(NT), 0, st,
-                           ws.tile_pinned, ws.tiles_x, ws.tiles_y, ws.flag, ws.list[0],
-                           ws.counts, 1);
-    } else {
-        hipLaunchKernelGGL(fill_seed_rows_kernel, dim3(tile_blocks), dim3(NT), 0, st,
-                           ws.tiles_x, ws.tiles_y, H,
-                           flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM), ws.flag,
-                           ws.list[0], ws.counts, 1);
+    if (!warm) {
+        hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
+        const size_t n = (size_t)H * W;
+        hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
+                           dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
+                           flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);
+    }
+    int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
+    const bool did_async = use_async && ws.ntiles > 0;
+    if (did_async) {
+        // ---- asynchronous phase: does (nearly) all of the work -------------------
+        hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
+                           ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1, ws.state,
+                           ws.prio, ws.pend, 0, ws.any);
+        const long long budget = 300000000ll;          // 3 s of the 100 MHz wall clock
+        hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
+        if (eps != 0.0f)
+            hipLaunchKernelGGL(fill_async_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H, W,
+                               eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state, ws.prio,
+                               ws.pend, ws.error, ws.stats, budget);
+        else
+            hipLaunchKernelGGL(fill_async_kernel<false>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
+                               W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
+                               ws.prio, ws.pend, ws.error, ws.stats, budget);
     }
     HDEM_HIP_CHECK(hipGetLastError());
-
-    const int grid = std::max(1, std::min(ws.ntiles, ctx->num_cus * 8));
-    int round = 0, converged = 0;
-    int64_t visits = 0;
-    while (round < max_rounds && !converged) {
+    // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
+    // behind the asynchronous phase every tile is checked once (mode 0 = all tiles);
+    // on its own it starts from the same seeds
+    if (ws.ntiles > 0)
+        hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
+                           ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
+                           ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any);
+    while (ws.ntiles > 0 && round < max_rounds && !converged) {
         for (int k = 0; k < K; ++k) {
             const int r = round + k;
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
             if (eps != 0.0f)
-                hipLaunchKernelGGL(fill_tile_kernel<true>, dim3(grid), dim3(NT), 0, st, z, w, H,
-                                   W, eps, ws.tiles_x, ws.tiles_y, ws.list[r & 1],
-                                   ws.counts + r, ws.list[(r + 1) & 1], ws.counts + r + 1,
-                                   ws.flag, r + 2);
+                hipLaunchKernelGGL(fill_round_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
+                                   W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
+                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats);
             else
-                hipLaunchKernelGGL(fill_tile_kernel<false>, dim3(grid), dim3(NT), 0, st, z, w,
-                                   H, W, eps, ws.tiles_x, ws.tiles_y, ws.list[r & 1],
-                                   ws.counts + r, ws.list[(r + 1) & 1], ws.counts + r + 1,
-                                   ws.flag, r + 2);
+                hipLaunchKernelGGL(fill_round_kernel<false>, dim3(ws.G), dim3(NT), 0, st, z, w,
+                                   H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
+                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats);
         }
         HDEM_HIP_CHECK(hipGetLastError());
-        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.counts + round,
-                                      (K + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.any + round, (K + 1) * sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
         for (int k = 0; k < K; ++k) {
             if (ctx->host_counts[k] == 0) { converged = 1; break; }
-            visits += ctx->host_counts[k];
             ++round;
         }
         if (!converged && ctx->host_counts[K] == 0) converged = 1;
     }
-    ctx->stats[HDEM_K_FILL_TILE].units += visits * FT * FT;
+    // ---- statistics ----------------------------------------------------------------
+    const size_t stat_words = (size_t)ws.G * STAT_WORDS;
+    unsigned long long *hs = (unsigned long long *)ctx->host_counts;
+    HDEM_HIP_CHECK(hipMemcpyAsync(hs, ws.stats, stat_words * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, st));
+    HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
+    HDEM_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long tot[STAT_WORDS] = {};
+    for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
+    ctx->stats[HDEM_K_FILL_TILE].units += (int64_t)tot[0] * FT * FT;
+    if (trace)
+        fprintf(stderr, "sink fill: visits %llu iterations %llu unchanged %llu requeued %llu, "
+                        "sync rounds %d, async_error %d; async busy %.3f ms idle %.3f ms per "
+                        "workgroup (G=%d)\n", tot[0], tot[1], tot[2], tot[3], round, async_error,
+                tot[4] / 1e5 / ws.G, tot[5] / 1e5 / ws.G, ws.G);
+#ifdef HDEM_VISIT_PROF
+    if (trace && tot[0])
+        fprintf(stderr, "  per-visit us (sync visits): load %.2f check %.2f zt %.2f iterate %.2f "
+                        "store %.2f wake-tests %.2f (changed visits %llu)\n",
+                tot[6] / 100.0 / tot[0], tot[7] / 100.0 / tot[0],
+                tot[8] / 100.0 / (tot[0] - tot[2] + 1), tot[9] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[10] / 100.0 / (tot[0] - tot[2] + 1), tot[11] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[0] - tot[2]);
+#endif
     if (stats) {
         stats->rounds = round;
         stats->converged = converged;
-        stats->tile_visits = visits;
+        stats->tile_visits = (int64_t)tot[0];
         stats->tiles = ws.ntiles;
         stats->tile_h = FT;
         stats->tile_w = FT;
         stats->scans = 0;
-        stats->reserved = 0;
+        stats->reserved = async_error;
+        stats->iterations = (int64_t)tot[1];
+        stats->visits_unchanged = (int64_t)tot[2];
+        stats->visits_requeued = (int64_t)tot[3];
     }
     if (!converged) {
         hdem_set_error("sink fill did not converge in %d rounds", max_rounds);

@@ -98,6 +98,9 @@ typedef struct hdem_fill_stats {
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
     int32_t scans;            /* directional scan launches                   */
     int32_t reserved;
+    int64_t iterations;       /* 4-scan iterations, summed over tile visits  */
+    int64_t visits_unchanged; /* visits that found nothing to lower          */
+    int64_t visits_requeued;  /* visits that hit the iteration cap           */
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */
@@ -108,6 +111,7 @@ typedef struct hdem_fill_stats {
 #define HDEM_FILL_ACT_BOTTOM  0x4  /* ... and/or row H-2 start active (after a halo       */
                                    /* exchange replaced ghost row 0 / H-1)                */
 #define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
+#define HDEM_FILL_SYNC_ONLY   0x40 /* skip the asynchronous phase (round-synchronous only) */
 #define HDEM_FILL_GHOST_TOP   0x10 /* INIT: row 0 / row H-1 is a ghost row owned by the   */
 #define HDEM_FILL_GHOST_BOTTOM 0x20 /* neighbouring row block: starts at +inf, not at Z    */
 

@@ -26,7 +26,7 @@ def main():
             cells = n * n
             print(f"n={n} gen={tg:.1f}s fill={tf*1e3:.2f}ms d8={td*1e3:.3f}ms "
                   f"-> {cells/(tf+td)/1e6:.0f} Mcells/s | rounds={st['rounds']} "
-                  f"visits={st['tile_visits']} ({st['tile_visits']/st['tiles']:.2f}/tile) "
+                  f"visits={st['tile_visits']} ({st['tile_visits']/st['tiles']:.2f}/tile) iters={st['iterations']} unchanged={st['visits_unchanged']} requeued={st['visits_requeued']} "
                   f"tile_kernel={kt['ms']:.2f}ms launches={kt['launches']} "
                   f"GB/s={12*kt['units']/max(kt['ms'],1e-9)/1e6:.0f} "
                   f"init={ki['ms']:.3f}ms scan={ks['ms']:.3f}ms d8k={k8['ms']:.3f}ms "

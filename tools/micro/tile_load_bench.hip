@@ -1,0 +1,80 @@
+// Exploration: how fast can one-wave-per-tile 64x64 window loads go?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s: %s\n",#x,hipGetErrorString(e)); return 1;}}while(0)
+
+template <int STEP, int VARIANT>
+__global__ __launch_bounds__(64, 2) void k(const float* __restrict__ z, const float* __restrict__ w, float* out,
+                                           int H, int W, int tiles_x, int ntiles)
+{
+    const int lane = threadIdx.x;
+    float acc = 0.f;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * STEP, x0 = tx * STEP;
+        if (VARIANT == 0) {            // dword per lane, row per instruction (current kernel)
+            float a[64], b[64];
+            const int xc = min(x0 + lane, W - 1);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+                a[r] = z[o]; b[r] = w[o];
+            }
+#pragma unroll
+            for (int r = 0; r < 64; ++r) acc += a[r] * b[r];
+        } else if (VARIANT == 1) {     // float4 per lane: 4 rows x 64 cols per instruction
+            typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+            f4 a[16], b[16];
+            const int rr = lane >> 4, cc = (lane & 15) * 4;
+            const int xc = min(x0 + cc, W - 4);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const size_t o = (size_t)min(y0 + i * 4 + rr, H - 1) * W + xc;
+                a[i] = *(const f4*)(z + o); b[i] = *(const f4*)(w + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += a[i].x * b[i].x + a[i].y * b[i].y + a[i].z * b[i].z + a[i].w * b[i].w;
+        } else {                       // only one array (z), dword
+            float a[64];
+            const int xc = min(x0 + lane, W - 1);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) a[r] = z[(size_t)min(y0 + r, H - 1) * W + xc];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) acc += a[r];
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+template <int STEP, int VARIANT>
+int run(const char* name, const float* z, const float* w, float* out, int H, int W, int grid)
+{
+    int tiles_x = (W - 2 + STEP - 1) / STEP, tiles_y = (H - 2 + STEP - 1) / STEP, nt = tiles_x * tiles_y;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k<STEP, VARIANT>), dim3(grid), dim3(64), 0, 0, z, w, out, H, W, tiles_x, nt);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double bytes = (double)nt * 64 * 64 * 4 * (VARIANT == 2 ? 1 : 2);
+        if (rep == 2) printf("%-34s grid %6d: %.3f ms  %.0f GB/s (window bytes)\n", name, grid, ms, bytes / ms / 1e6);
+    }
+    return 0;
+}
+
+int main()
+{
+    const int H = 16384, W = 16384;
+    float *z, *w, *out;
+    CK(hipMalloc(&z, (size_t)H * W * 4)); CK(hipMalloc(&w, (size_t)H * W * 4)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(z, 0, (size_t)H * W * 4)); CK(hipMemset(w, 0, (size_t)H * W * 4));
+    for (int grid : {2048, 4096, 8192, 70225}) {
+        run<62, 0>("dword rows, step 62", z, w, out, H, W, grid);
+        run<64, 0>("dword rows, step 64 (aligned)", z, w, out, H, W, grid);
+        run<62, 1>("float4 4rows, step 62", z, w, out, H, W, grid);
+        run<64, 1>("float4 4rows, step 64", z, w, out, H, W, grid);
+        run<62, 2>("dword rows, one array, step 62", z, w, out, H, W, grid);
+    }
+    return 0;
+}
