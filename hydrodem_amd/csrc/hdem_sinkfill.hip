@@ -59,6 +59,7 @@ constexpr int NT = 64;             // one wave per workgroup
 constexpr int ITER_MAX = 8;        // 4-scan iterations before the tile re-queues
 constexpr int INIT_NT = 256;
 constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
+constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (agent scope)
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
 constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
 #ifdef HDEM_VISIT_PROF
@@ -113,26 +114,38 @@ struct scan_masks {                 // wave-uniform (SGPR) lane masks of changed
     unsigned long long first, last, all;
 };
 
-// One directional scan over the 64 lines held in registers.  Line i takes the
-// three neighbours on the previously visited line; lines 0 and 63 and lanes 0
-// and 63 are the pinned ring (z == w there, so med3 returns w).  Needs
-// z[i] <= w[i], which every valid upper bound of W* satisfies.
-template <bool HAS_EPS, bool FWD>
+// Two opposite directional scans over the 64 lines held in registers, interleaved
+// instruction by instruction: the forward chain walks lines 1..62 while the
+// backward chain walks 62..1.  Each step takes the three neighbours on the line its
+// own chain visited just before: two v_mov_dpp wave shifts, v_min3, v_med3, v_cmp.
+// A chain is latency-bound (each step waits on the previous one), so running the
+// two together costs little more than one.  Once the chains have crossed, each
+// walks over lines the other already lowered and simply uses the newer values.
+// Lines 0 and 63 and lanes 0 and 63 are the pinned ring (z == w there, so med3
+// returns w).  Needs z[i] <= w[i], which every valid upper bound of W* satisfies.
+template <bool HAS_EPS>
 __device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN], float eps,
                                            scan_masks &m)
 {
-    float prev = w[FWD ? 0 : WN - 1];
+    float pf = w[0], pb = w[WN - 1];
 #pragma unroll
     for (int k = 1; k <= WN - 2; ++k) {
-        const int i = FWD ? k : WN - 1 - k;
-        float c = fminf(fminf(prev, lane_prev(prev)), lane_next(prev));
-        if (HAS_EPS) c = c + eps;
-        const float n = __builtin_amdgcn_fmed3f(z[i], w[i], c);
-        if (i == 1) or_changed(m.first, n, w[i]);
-        else if (i == WN - 2) or_changed(m.last, n, w[i]);
-        else or_changed(m.all, n, w[i]);
-        w[i] = n;
-        prev = n;
+        const int i = k, j = WN - 1 - k;
+        float cf = fminf(fminf(pf, lane_prev(pf)), lane_next(pf));
+        float cb = fminf(fminf(pb, lane_prev(pb)), lane_next(pb));
+        if (HAS_EPS) { cf = cf + eps; cb = cb + eps; }
+        const float nf = __builtin_amdgcn_fmed3f(z[i], w[i], cf);
+        if (i == 1) or_changed(m.first, nf, w[i]);
+        else if (i == WN - 2) or_changed(m.last, nf, w[i]);
+        else or_changed(m.all, nf, w[i]);
+        w[i] = nf;
+        pf = nf;
+        const float nb = __builtin_amdgcn_fmed3f(z[j], w[j], cb);
+        if (j == 1) or_changed(m.first, nb, w[j]);
+        else if (j == WN - 2) or_changed(m.last, nb, w[j]);
+        else or_changed(m.all, nb, w[j]);
+        w[j] = nb;
+        pb = nb;
     }
 }
 
@@ -219,20 +232,27 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     const int lane = threadIdx.x;
     const int y0 = ty * FT, x0 = tx * FT;              // window origin (= halo row/col)
     const int x = x0 + lane;
+#ifdef HDEM_VISIT_PROF
+    const long long tprof_entry_ = wall_clock64();
+#endif
 
     // ---- load the window: lane = column -------------------------------------
     // Addresses are clamped into the raster instead of predicated, so that all 128
     // row loads of the lane are in flight together.
     float z[WN], w[WN];
     const int xc = min(x, W - 1);
+    // 32-bit byte offsets: the asynchronous driver is used for rasters below 4 GiB
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        wg, 0, COHERENT ? (int)(unsigned)((size_t)H * W * sizeof(float)) : 0, 0x00020000);
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
         z[r] = zg[o];
+        // (an agent-scope __hip_atomic_load is waited for one by one -- 64 serial round
+        // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
         if (COHERENT)
-            w[r] = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int *>(wg + o),
-                                                               __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT));
+            w[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                wrsrc, (unsigned)(o * sizeof(float)), 0, AUX_SC1));
         else
             w[r] = wg[o];
     }
@@ -253,7 +273,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     visit_result out;
 #ifdef HDEM_VISIT_PROF
     for (int k = 0; k < 6; ++k) out.ticks[k] = 0;
-    long long tprof_ = wall_clock64();
+    long long tprof_ = tprof_entry_;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PROF_MARK(0);
 #endif
@@ -274,11 +294,9 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         PROF_MARK(2);
         for (; out.iters < ITER_MAX && more; ++out.iters) {
             scan_masks v = {0, 0, 0}, h = {0, 0, 0};
-            scan_lines<HAS_EPS, true>(z, w, eps, v);   // north -> south
-            scan_lines<HAS_EPS, false>(z, w, eps, v);  // south -> north
+            scan_lines<HAS_EPS>(z, w, eps, v);         // north -> south and south -> north
             transpose(w, T, lane);
-            scan_lines<HAS_EPS, true>(zt, w, eps, h);  // west -> east
-            scan_lines<HAS_EPS, false>(zt, w, eps, h); // east -> west
+            scan_lines<HAS_EPS>(zt, w, eps, h);        // west -> east and east -> west
             // back to lane = column
 #pragma unroll
             for (int i = 0; i < WN; ++i) T[lane * TS + i] = w[i];
@@ -309,9 +327,9 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
                 if (y <= H - 2) {
                     const float val = z[r] == HDEM_INF ? __builtin_nanf("") : w[r];
                     if (COHERENT)
-                        __hip_atomic_store(reinterpret_cast<int *>(wg + (size_t)y * W + x),
-                                           __builtin_bit_cast(int, val), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __builtin_bit_cast(unsigned, val), wrsrc,
+                            (unsigned)(((size_t)y * W + x) * sizeof(float)), 0, AUX_SC1);
                     else
                         wg[(size_t)y * W + x] = val;
                 }
@@ -606,8 +624,8 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         now = wall_clock64();
 #ifdef HDEM_VISIT_PROF
         if (threadIdx.x == 8) {
-            for (int k = 1; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
-            stats[(size_t)b * STAT_WORDS + 6] += (unsigned long long)(now - t_v);   // finish
+            for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
+            stats[(size_t)b * STAT_WORDS + 11] += (unsigned long long)(now - t_v);   // + finish
         }
 #endif
         busy += now - t_mark;
@@ -759,7 +777,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (max_rounds <= 0) max_rounds = 1 << 16;
     const int K = 8;   // rounds enqueued between convergence checks
     max_rounds = (max_rounds + K - 1) / K * K;
-    const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr;
+    const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr &&
+                           (size_t)H * W * sizeof(float) < (size_t)0xffffffffu;
     const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
 
     fill_ws ws;

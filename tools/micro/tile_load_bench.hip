@@ -10,10 +10,12 @@ __global__ __launch_bounds__(64, 2) void k(const float* __restrict__ z, const fl
 {
     const int lane = threadIdx.x;
     float acc = 0.f;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+        // VARIANT >= 10: scrambled visiting order (what the asynchronous driver produces)
+        const int t = VARIANT >= 10 ? (int)(((unsigned long long)t0 * 40503ull) % (unsigned)ntiles) : t0;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int y0 = ty * STEP, x0 = tx * STEP;
-        if (VARIANT == 0) {            // dword per lane, row per instruction (current kernel)
+        if (VARIANT == 0 || VARIANT == 10) {            // dword per lane, row per instruction (current kernel)
             float a[64], b[64];
             const int xc = min(x0 + lane, W - 1);
 #pragma unroll
@@ -35,6 +37,44 @@ __global__ __launch_bounds__(64, 2) void k(const float* __restrict__ z, const fl
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc += a[i].x * b[i].x + a[i].y * b[i].y + a[i].z * b[i].z + a[i].w * b[i].w;
+        } else if (VARIANT == 3) {     // dword rows, w via sc1 (agent-scope relaxed atomic) loads
+            float a[64], b[64];
+            const int xc = min(x0 + lane, W - 1);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+                a[r] = z[o];
+                b[r] = __builtin_bit_cast(float, __hip_atomic_load((const int*)(w + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+#pragma unroll
+            for (int r = 0; r < 64; ++r) acc += a[r] * b[r];
+        } else if (VARIANT == 4) {     // load + sc1 store of the interior (62 rows)
+            float a[64], b[64];
+            const int xc = min(x0 + lane, W - 1);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+                a[r] = z[o];
+                b[r] = __builtin_bit_cast(float, __hip_atomic_load((const int*)(w + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            if (lane >= 1 && lane <= 62 && x0 + lane < W - 1) {
+#pragma unroll
+                for (int r = 1; r < 63; ++r) if (y0 + r < H - 1)
+                    __hip_atomic_store((int*)(w + (size_t)(y0 + r) * W + x0 + lane), __builtin_bit_cast(int, a[r] + b[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (VARIANT == 5) {     // load + plain store
+            float a[64], b[64];
+            const int xc = min(x0 + lane, W - 1);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+                a[r] = z[o]; b[r] = w[o];
+            }
+            if (lane >= 1 && lane <= 62 && x0 + lane < W - 1) {
+#pragma unroll
+                for (int r = 1; r < 63; ++r) if (y0 + r < H - 1)
+                    ((float*)w)[(size_t)(y0 + r) * W + x0 + lane] = a[r] + b[r];
+            }
         } else {                       // only one array (z), dword
             float a[64];
             const int xc = min(x0 + lane, W - 1);
@@ -69,12 +109,16 @@ int main()
     float *z, *w, *out;
     CK(hipMalloc(&z, (size_t)H * W * 4)); CK(hipMalloc(&w, (size_t)H * W * 4)); CK(hipMalloc(&out, 64));
     CK(hipMemset(z, 0, (size_t)H * W * 4)); CK(hipMemset(w, 0, (size_t)H * W * 4));
-    for (int grid : {2048, 4096, 8192, 70225}) {
+    for (int grid : {2048, 70225}) {
         run<62, 0>("dword rows, step 62", z, w, out, H, W, grid);
         run<64, 0>("dword rows, step 64 (aligned)", z, w, out, H, W, grid);
         run<62, 1>("float4 4rows, step 62", z, w, out, H, W, grid);
         run<64, 1>("float4 4rows, step 64", z, w, out, H, W, grid);
         run<62, 2>("dword rows, one array, step 62", z, w, out, H, W, grid);
+        run<62, 3>("dword rows, w sc1 loads", z, w, out, H, W, grid);
+        run<62, 10>("dword rows, scrambled order", z, w, out, H, W, grid);
+        run<62, 4>("sc1 loads + sc1 stores", z, w, out, H, W, grid);
+        run<62, 5>("plain loads + plain stores", z, w, out, H, W, grid);
     }
     return 0;
 }
