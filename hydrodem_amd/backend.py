@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhydrodem_hip.so")
 OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = range(8)
 
 # kernel ids for the timing query
-K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN = range(7)
+K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY = 0x10, 0x20, 0x40
@@ -38,12 +38,12 @@ class FillStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_int32), ("converged", ctypes.c_int32),
                 ("tile_visits", ctypes.c_int64), ("tiles", ctypes.c_int64),
                 ("tile_h", ctypes.c_int32), ("tile_w", ctypes.c_int32),
-                ("scans", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("scans", ctypes.c_int32), ("async_timed_out", ctypes.c_int32),
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
-                ("visits_requeued", ctypes.c_int64)]
+                ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 _c = ctypes

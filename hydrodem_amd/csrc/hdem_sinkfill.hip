@@ -63,10 +63,11 @@ constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
 constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
 #ifdef HDEM_VISIT_PROF
-constexpr int STAT_WORDS = 12;
+constexpr int STAT_WORDS = 13;
 #else
-constexpr int STAT_WORDS = 6;      // per workgroup: visits, iterations, unchanged, re-queued,
-                                   // busy ticks, idle ticks (100 MHz, async driver)
+constexpr int STAT_WORDS = 7;      // per workgroup: visits, iterations, unchanged, re-queued,
+                                   // busy ticks, idle ticks (100 MHz, async driver),
+                                   // visits made by the round driver
 #endif
 enum { ST_IDLE = 0, ST_QUEUED = 1, ST_RUNNING = 2, ST_DIRTY = 3, ST_ROUND0 = 16 };
 
@@ -471,8 +472,9 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
                     *any_next = 1;
                 }
                 add_stats(stats, b, v.changed, v.more, v.iters);
+                stats[(size_t)b * STAT_WORDS + 6] += 1;
 #ifdef HDEM_VISIT_PROF
-                for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
+                for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 7 + k] += v.ticks[k];
 #endif
             }
         }
@@ -624,8 +626,8 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         now = wall_clock64();
 #ifdef HDEM_VISIT_PROF
         if (threadIdx.x == 8) {
-            for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 6 + k] += v.ticks[k];
-            stats[(size_t)b * STAT_WORDS + 11] += (unsigned long long)(now - t_v);   // + finish
+            for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 7 + k] += v.ticks[k];
+            stats[(size_t)b * STAT_WORDS + 12] += (unsigned long long)(now - t_v);   // + finish
         }
 #endif
         busy += now - t_mark;
@@ -824,7 +826,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     while (ws.ntiles > 0 && round < max_rounds && !converged) {
         for (int k = 0; k < K; ++k) {
             const int r = round + k;
-            hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
+            hdem_scoped_timer tm(ctx, HDEM_K_FILL_ROUND, 0);
             if (eps != 0.0f)
                 hipLaunchKernelGGL(fill_round_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                    W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
@@ -853,7 +855,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     HDEM_HIP_CHECK(hipStreamSynchronize(st));
     unsigned long long tot[STAT_WORDS] = {};
     for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
-    ctx->stats[HDEM_K_FILL_TILE].units += (int64_t)tot[0] * FT * FT;
+    ctx->stats[HDEM_K_FILL_TILE].units += (int64_t)(tot[0] - tot[6]) * FT * FT;
+    ctx->stats[HDEM_K_FILL_ROUND].units += (int64_t)tot[6] * FT * FT;
     if (trace)
         fprintf(stderr, "sink fill: visits %llu iterations %llu unchanged %llu requeued %llu, "
                         "sync rounds %d, async_error %d; async busy %.3f ms idle %.3f ms per "
@@ -863,9 +866,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (trace && tot[0])
         fprintf(stderr, "  per-visit us (sync visits): load %.2f check %.2f zt %.2f iterate %.2f "
                         "store %.2f wake-tests %.2f (changed visits %llu)\n",
-                tot[6] / 100.0 / tot[0], tot[7] / 100.0 / tot[0],
-                tot[8] / 100.0 / (tot[0] - tot[2] + 1), tot[9] / 100.0 / (tot[0] - tot[2] + 1),
-                tot[10] / 100.0 / (tot[0] - tot[2] + 1), tot[11] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[7] / 100.0 / tot[0], tot[8] / 100.0 / tot[0],
+                tot[9] / 100.0 / (tot[0] - tot[2] + 1), tot[10] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[11] / 100.0 / (tot[0] - tot[2] + 1), tot[12] / 100.0 / (tot[0] - tot[2] + 1),
                 tot[0] - tot[2]);
 #endif
     if (stats) {
@@ -876,10 +879,11 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         stats->tile_h = FT;
         stats->tile_w = FT;
         stats->scans = 0;
-        stats->reserved = async_error;
+        stats->async_timed_out = async_error;
         stats->iterations = (int64_t)tot[1];
         stats->visits_unchanged = (int64_t)tot[2];
         stats->visits_requeued = (int64_t)tot[3];
+        stats->round_visits = (int64_t)tot[6];
     }
     if (!converged) {
         hdem_set_error("sink fill did not converge in %d rounds", max_rounds);

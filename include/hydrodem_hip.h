@@ -65,11 +65,12 @@ int hdem_memcpy_d2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 typedef enum hdem_kernel_id {
     HDEM_K_D8 = 0,
     HDEM_K_FILL_INIT = 1,
-    HDEM_K_FILL_TILE = 2,     /* the sink-fill tile relaxation (dominant)   */
+    HDEM_K_FILL_TILE = 2,     /* sink fill: asynchronous tile relaxation (dominant) */
     HDEM_K_BOXMEAN = 3,
     HDEM_K_GROVES = 4,        /* fused quadratic + groves epilogue          */
     HDEM_K_CONVOLVE = 5,
-    HDEM_K_FILL_SCAN = 6,     /* directional upper-bound scans              */
+    HDEM_K_FILL_SCAN = 6,     /* (reserved)                                 */
+    HDEM_K_FILL_ROUND = 7,    /* round-synchronous certifying / finishing pass */
     HDEM_K_COUNT = 8
 } hdem_kernel_id;
 
@@ -91,16 +92,17 @@ int hdem_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, uint8_t *out);
 
 /* ---- A1  SinkFill.apply  (new operator; no reference body -- SURVEY F2) -- */
 typedef struct hdem_fill_stats {
-    int32_t rounds;           /* worklist rounds executed                    */
-    int32_t converged;        /* 1 when the worklist drained                 */
-    int64_t tile_visits;      /* tiles relaxed, summed over rounds           */
+    int32_t rounds;           /* round-synchronous launches that had work      */
+    int32_t converged;        /* 1 when a round found nothing left to do       */
+    int64_t tile_visits;      /* tile visits, both drivers                     */
     int64_t tiles;            /* tiles in the raster                         */
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
     int32_t scans;            /* directional scan launches                   */
-    int32_t reserved;
+    int32_t async_timed_out;  /* 1: the asynchronous launch hit its wall-clock budget  */
     int64_t iterations;       /* 4-scan iterations, summed over tile visits  */
     int64_t visits_unchanged; /* visits that found nothing to lower          */
     int64_t visits_requeued;  /* visits that hit the iteration cap           */
+    int64_t round_visits;     /* of tile_visits: made by the round driver    */
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */

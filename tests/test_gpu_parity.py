@@ -91,6 +91,23 @@ def test_sinkfill_matches_priority_flood(shape, variant):
     assert f.stats["converged"] == 1
 
 
+def test_sinkfill_round_driver_alone():
+    """HDEM_FILL_SYNC_ONLY: the round-synchronous driver (the certifying pass of the
+    default path) must reach the same fixed point on its own."""
+    z = oracle.synth_dem(700, 900)
+    want = c_oracle.sinkfill_pflood(z)
+    with backend.DeviceRaster.from_host(z) as zd:
+        out, st = backend.sinkfill_dev(zd, flags=backend.FILL_SYNC_ONLY)
+        got = out.to_host()
+        out.free()
+    assert np.array_equal(got, want)
+    assert st["converged"] == 1 and st["rounds"] > 3          # it really iterated rounds
+    got2, st2 = backend.sinkfill(z, return_stats=True)         # default: async + 1 certifying round
+    assert np.array_equal(got2, want)
+    assert st2["async_timed_out"] == 0                                # no wall-clock bail-out
+    assert st2["rounds"] <= 3
+
+
 def test_sinkfill_matches_jacobi_definition():
     z = oracle.synth_dem(96, 140)
     want, _ = oracle.sinkfill_jacobi(z)
