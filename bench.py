@@ -108,8 +108,13 @@ def main():
         import torch
         import torch.distributed as dist
         from hydrodem_amd import partition as P
+        # HDEM_REHEARSE=1: every rank on cuda:0 over gloo -- lets the N > 1 code path
+        # be exercised on a one-GPU box; never a performance number
+        rehearse = os.environ.get("HDEM_REHEARSE") == "1"
+        if rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if rehearse else "nccl")
         H = N * S
         g0, g1, top, bottom = P.local_range(rank, world, H)
         z = oracle.synth_dem(H, S, row0=g0, rows=g1 - g0)
@@ -132,7 +137,7 @@ def main():
             torch.cuda.synchronize()
 
         def reduce_max(x):
-            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 

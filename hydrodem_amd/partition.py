@@ -70,20 +70,27 @@ class HipLocalSolver:
 
 def _exchange(dist, torch, w, top, bottom, rank):
     """Swap boundary rows with the neighbours; returns (top_changed,
-    bottom_changed) as Python bools.  One batched isend/irecv group."""
+    bottom_changed) as Python bools.  One batched isend/irecv group.  Under the
+    gloo backend device tensors are staged through the host (gloo has no device
+    point-to-point); that is the rehearsal path, RCCL moves device memory."""
     ops, recv_top, recv_bot = [], None, None
     h = w.shape[0]
+    stage = w.is_cuda and dist.get_backend() == "gloo"
+    buf_dev = torch.device("cpu") if stage else w.device
     if top:
-        recv_top = torch.empty_like(w[0])
-        ops.append(dist.P2POp(dist.isend, w[1].contiguous(), rank - 1))
+        recv_top = torch.empty(w.shape[1], dtype=w.dtype, device=buf_dev)
+        ops.append(dist.P2POp(dist.isend, w[1].to(buf_dev).contiguous(), rank - 1))
         ops.append(dist.P2POp(dist.irecv, recv_top, rank - 1))
     if bottom:
-        recv_bot = torch.empty_like(w[h - 1])
-        ops.append(dist.P2POp(dist.isend, w[h - 2].contiguous(), rank + 1))
+        recv_bot = torch.empty(w.shape[1], dtype=w.dtype, device=buf_dev)
+        ops.append(dist.P2POp(dist.isend, w[h - 2].to(buf_dev).contiguous(), rank + 1))
         ops.append(dist.P2POp(dist.irecv, recv_bot, rank + 1))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if stage:
+        recv_top = recv_top.to(w.device) if top else None
+        recv_bot = recv_bot.to(w.device) if bottom else None
     # NaN (nodata) never compares equal: compare bit patterns
     flags = torch.zeros(2, dtype=torch.int32, device=w.device)
     if top:
@@ -118,8 +125,9 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     while True:
         if world > 1:
             ch_top, ch_bot = _exchange(dist, torch, w, top, bottom, rank)
+            flag_dev = "cpu" if dist.get_backend() == "gloo" else w.device
             any_changed = torch.tensor([int(ch_top or ch_bot)], dtype=torch.int32,
-                                       device=w.device)
+                                       device=flag_dev)
             dist.all_reduce(any_changed, op=dist.ReduceOp.MAX, group=group)
             exchanges += 1
             if int(any_changed.item()) == 0:
