@@ -26,7 +26,7 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
-FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY = 0x10, 0x20, 0x40
+FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
 
 
 class KernelStat(ctypes.Structure):

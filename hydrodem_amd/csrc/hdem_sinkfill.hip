@@ -556,9 +556,10 @@ __device__ __attribute__((noinline)) int async_pick(int b, int G, int S, int nti
         for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o);
         if (p <= 0) { if (++zero_reads >= 2) return -1; } else zero_reads = 0;
         if (wall_clock64() - t_begin > budget_ticks) {
-            if (lane == 0) atomicExch(error, 1);
+            if (lane == 0) atomicCAS(error, 0, 1);
             return -1;
         }
+        if (ld_relaxed(error) != 0) return -1;
         __builtin_amdgcn_s_sleep(32);
     }
 }
@@ -606,6 +607,17 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
     __shared__ float T[WN * TS];
     const int G = gridDim.x, b = blockIdx.x;
     const long long t_begin = wall_clock64();
+    // Residency census.  The schedule below needs every workgroup running at once
+    // (a tile is only ever relaxed by its owner).  A grid of 8 single-wave workgroups
+    // per CU is resident on an otherwise idle MI355X, but not when the GPU is shared:
+    // if the others do not show up within 200 us, give up here -- the host then runs
+    // the round-synchronous driver, which needs no co-residency.
+    if (threadIdx.x == 0) atomicAdd(error + 1, 1);
+    while (ld_relaxed(error + 1) < G && ld_relaxed(error) == 0) {
+        if (wall_clock64() - t_begin > 20000) { atomicExch(error, 2); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (ld_relaxed(error) != 0) return;
     long long t_mark = t_begin, busy = 0, idle = 0;
     for (;;) {
         // readfirstlane: the tile index is wave-uniform; say so, or every row address
@@ -804,7 +816,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1, ws.state,
                            ws.prio, ws.pend, 0, ws.any);
-        const long long budget = 300000000ll;          // 3 s of the 100 MHz wall clock
+        // wall-clock budget (100 MHz ticks): generous against the ~0.15 us per tile a
+        // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second
+        const long long budget = 20000000ll + (long long)ws.ntiles * 200ll;
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
         if (eps != 0.0f)
             hipLaunchKernelGGL(fill_async_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H, W,
@@ -819,11 +833,18 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
     // behind the asynchronous phase every tile is checked once (mode 0 = all tiles);
     // on its own it starts from the same seeds
-    if (ws.ntiles > 0)
+    bool verify = !(did_async && (flags & HDEM_FILL_NO_VERIFY));
+    if (!verify) {
+        // trust the asynchronous phase unless it ran out of its wall-clock budget
+        HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
+        HDEM_HIP_CHECK(hipStreamSynchronize(st));
+        if (async_error) verify = true; else converged = 1;
+    }
+    if (ws.ntiles > 0 && verify)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
                            ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any);
-    while (ws.ntiles > 0 && round < max_rounds && !converged) {
+    while (ws.ntiles > 0 && verify && round < max_rounds && !converged) {
         for (int k = 0; k < K; ++k) {
             const int r = round + k;
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_ROUND, 0);

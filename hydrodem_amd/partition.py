@@ -13,7 +13,9 @@ elsewhere -- which is exactly what the single-GPU solver pins.
 
 Sink fill.  repeat { relax the local block to its fixed point with the ghost
 rows frozen ; swap boundary rows with rank+-1 (point-to-point, W*4 bytes each
-way) ; all-reduce one "any ghost row changed" flag } until the flag is clear.
+way) ; all-reduce one "any ghost row changed" flag } until the flag is clear;
+then every rank runs one verifying pass over its whole block (the intermediate
+solves skip it) and the loop resumes only if that pass lowered something.
 Legal for any interleaving because the relaxation is monotone from above
 (stale ghost rows are upper bounds: they delay, never corrupt), and the state
 at exit is a fixed point of the global operator, hence the same bits as the
@@ -60,9 +62,10 @@ class HipLocalSolver:
                                          ctx=self.ctx, keepalive=t)
 
     def fill(self, z, w, eps, flags):
+        """Returns (tile visits, whether any cell was lowered)."""
         _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
                                      out=self._wrap(w, np.float32), flags=flags)
-        return st["tile_visits"]
+        return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"]
 
     def d8(self, w, out):
         backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
@@ -120,27 +123,38 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         flags |= backend.FILL_GHOST_TOP
     if bottom:
         flags |= backend.FILL_GHOST_BOTTOM
-    visits = solver.fill(z_local, w, eps, flags)
-    exchanges = 0
-    while True:
-        if world > 1:
-            ch_top, ch_bot = _exchange(dist, torch, w, top, bottom, rank)
+    flag_dev = None
+    visits, _ = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY)
+    exchanges = verifications = 0
+    while world > 1:
+        ch_top, ch_bot = _exchange(dist, torch, w, top, bottom, rank)
+        if flag_dev is None:
             flag_dev = "cpu" if dist.get_backend() == "gloo" else w.device
-            any_changed = torch.tensor([int(ch_top or ch_bot)], dtype=torch.int32,
-                                       device=flag_dev)
-            dist.all_reduce(any_changed, op=dist.ReduceOp.MAX, group=group)
-            exchanges += 1
-            if int(any_changed.item()) == 0:
+        any_changed = torch.tensor([int(ch_top or ch_bot)], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(any_changed, op=dist.ReduceOp.MAX, group=group)
+        exchanges += 1
+        if exchanges >= max_exchanges:
+            raise RuntimeError("distributed sink fill did not converge")
+        if int(any_changed.item()) == 0:
+            # every rank is at rest: certify the whole block (round driver, all tiles
+            # due); resume only if some rank still found something to lower
+            v, lowered = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+            visits += v
+            verifications += 1
+            again = torch.tensor([int(lowered)], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(again, op=dist.ReduceOp.MAX, group=group)
+            if int(again.item()) == 0:
                 break
-            if ch_top or ch_bot:
-                flags = backend.FILL_WARM
-                flags |= backend.FILL_ACT_TOP if ch_top else 0
-                flags |= backend.FILL_ACT_BOTTOM if ch_bot else 0
-                visits += solver.fill(z_local, w, eps, flags)
-            if exchanges >= max_exchanges:
-                raise RuntimeError("distributed sink fill did not converge")
-        else:
-            break
+            continue
+        if ch_top or ch_bot:
+            act = backend.FILL_WARM | backend.FILL_NO_VERIFY
+            act |= backend.FILL_ACT_TOP if ch_top else 0
+            act |= backend.FILL_ACT_BOTTOM if ch_bot else 0
+            v, _ = solver.fill(z_local, w, eps, act)
+            visits += v
+    if world == 1:
+        v, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+        visits += v
     return w, {"tile_visits": int(visits), "exchanges": exchanges}
 
 

@@ -114,6 +114,9 @@ typedef struct hdem_fill_stats {
                                    /* exchange replaced ghost row 0 / H-1)                */
 #define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
 #define HDEM_FILL_SYNC_ONLY   0x40 /* skip the asynchronous phase (round-synchronous only) */
+#define HDEM_FILL_NO_VERIFY   0x80 /* skip the certifying round pass behind the asynchronous
+                                      phase: for intermediate solves of a halo-exchange loop
+                                      whose last solve is a verifying one                  */
 #define HDEM_FILL_GHOST_TOP   0x10 /* INIT: row 0 / row H-1 is a ghost row owned by the   */
 #define HDEM_FILL_GHOST_BOTTOM 0x20 /* neighbouring row block: starts at +inf, not at Z    */
 

@@ -38,7 +38,7 @@ class NumpyLocalSolver:
             wn[:] = new
             sweeps += 1
             if changed == 0:
-                return sweeps
+                return sweeps, sweeps > 1
 
     def d8(self, w, out):
         out.numpy()[:] = oracle.d8_flow_direction(w.numpy())
