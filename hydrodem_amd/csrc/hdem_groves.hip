@@ -13,7 +13,10 @@
 // tile centre), which keeps float32 accumulation ~1e-6 m from exact math (the
 // reference itself sits 5e-5 m from exact math: float32 s1).
 //
-// Kernel shape (gfx950): one 256-thread workgroup per 64 x 32 output tile.
+// Two kernels evaluate it: groves_stream_kernel (ws = 3, 9, 15: the production
+// window) and the tiled groves_kernel below for the other odd sizes up to 31.
+//
+// Tiled kernel shape (gfx950): one 256-thread workgroup per 64 x 32 output tile.
 //   phase 0  stage the (32+2p) x (64+2p) input window in LDS as d = w - c0;
 //   phase 1  row sums R0/R2 for every staged row, 4 adjacent columns per item
 //            from aligned ds_read_b128 runs, results to two LDS planes;
@@ -141,6 +144,188 @@ __global__ __launch_bounds__(NT) void groves_kernel(const float *__restrict__ im
     }
 }
 
+// ---------------------------------------------------------------------------
+// Streaming form of the same arithmetic (used for ws <= 15).  One WAVE owns a
+// 256-column x 128-row strip and walks down its input rows once:
+//   * lane l holds columns 4l..4l+3 as one float4 (a wave-level load is 1 KiB of
+//     one raster row); lanes 0..2p-1 also fetch one halo column each; rows are
+//     prefetched three ahead so ~3 KiB per wave are always in flight;
+//   * the row (as d = w - c0) goes through a wave-private LDS row buffer (two
+//     alternating slots, no workgroup barrier) from which each lane reads the
+//     4+2p values around its columns as aligned ds_read_b128;
+//   * the row sums R0/R2 feed a ring of `ws` vertical accumulators per column held
+//     in registers (slot = output row mod ws, static after unrolling by ws): the
+//     output row that receives its last term is finished, blended and stored.
+// HBM reads are the raster once plus (128+2p)/128 row overlap (1.11x at ws = 15)
+// instead of the 1.75x of the tiled kernel; no tile is staged twice.
+// ---------------------------------------------------------------------------
+constexpr int SW_COLS = 256;     // strip width  (cells) = 64 lanes x 4
+constexpr int SR_ROWS = 128;     // strip height (output rows)
+
+template <int WS>
+__global__ __launch_bounds__(NT) void groves_stream_kernel(const float *__restrict__ img,
+                                                          const uint8_t *__restrict__ groves,
+                                                          int H, int W, float thr,
+                                                          int strips_x, int nstrips,
+                                                          quad_coef cf, float *__restrict__ out)
+{
+    constexpr int P = WS / 2;
+    constexpr int PADL = (P + 3) / 4 * 4;                 // interior starts 16-byte aligned
+    constexpr int OFF = PADL - P;                         // first needed float, from the aligned read
+    constexpr int NRD = (OFF + 4 + 2 * P + 3) / 4;        // ds_read_b128 per lane per row
+    constexpr int RB = (PADL + SW_COLS + P + 3) / 4 * 4 + 4;   // row buffer (floats)
+    constexpr int PF = 3;                                 // rows in flight (divides the unroll)
+    static_assert(WS % PF == 0 || WS < PF, "prefetch ring must divide the unroll");
+    constexpr int NSLOT = 8;                              // >= p + 1 rows of history (ws <= 15)
+    static_assert(P + 1 <= NSLOT, "row ring too short");
+    __shared__ __attribute__((aligned(16))) float rows[4][NSLOT][RB];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip >= nstrips) return;
+    const int sy = strip / strips_x, sx = strip - sy * strips_x;
+    const int x0 = sx * SW_COLS, y0 = sy * SR_ROWS;
+    const int x = x0 + 4 * lane;
+    float *rb = &rows[wave][0][0];
+    const bool vec_ok = x + 4 <= W;
+
+    float c0 = img[(size_t)min(y0 + SR_ROWS / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
+    if (!(fabsf(c0) < HDEM_INF)) c0 = 0.0f;
+
+    // halo column of this lane (lanes 0..2p-1): left halo x0-p+lane, right x0+256+(lane-p)
+    const bool has_halo = lane < 2 * P;
+    const int hx = min(max(lane < P ? x0 - P + lane : x0 + SW_COLS + lane - P, 0), W - 1);
+    const int hidx = lane < P ? OFF + lane : PADL + SW_COLS + lane - P;
+
+    auto load_row = [&](int i, hdem_f4 &v, float &hv) {
+        const int y = min(max(y0 - P + i, 0), H - 1);
+        const float *row = img + (size_t)y * W;
+        if (x + 4 <= W) {
+            v = hdem_ld4u(row + x);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = row[min(x + k, W - 1)];
+        }
+        hv = has_halo ? row[hx] : 0.0f;
+    };
+
+    // accumulators as float2 pairs: the vertical update is v_pk_add + v_pk_fma
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[WS][2];
+#pragma unroll
+    for (int j = 0; j < WS; ++j) { acc[j][0] = (f2){0.0f, 0.0f}; acc[j][1] = (f2){0.0f, 0.0f}; }
+
+    // groves bytes of the output row that completes at step i (row y0 + i - 2p), fetched
+    // PF steps ahead like the image rows: nothing in the loop waits on a fresh load
+    auto load_mask = [&](int i) -> unsigned {
+        const int y = y0 + i - 2 * P;
+        unsigned g = 0;
+        if (groves && y >= 0 && y < H && x < W) {
+            const size_t gi = (size_t)y * W + x;
+            if (vec_ok && (gi & 3) == 0) g = *reinterpret_cast<const unsigned *>(groves + gi);
+            else
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < W) g |= (unsigned)groves[gi + k] << (8 * k);
+        }
+        return g;
+    };
+
+    hdem_f4 pre[PF];
+    float preh[PF];
+    unsigned preg[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) { load_row(k, pre[k], preh[k]); preg[k] = load_mask(k); }
+
+    constexpr int NROWS = SR_ROWS + 2 * P;
+    for (int base = 0; base < NROWS; base += WS) {
+#pragma unroll
+        for (int u = 0; u < WS; ++u) {
+            const int i = base + u;
+            // ---- row i: registers -> LDS row slot, next prefetch ------------------
+            float *slot = rb + (i & (NSLOT - 1)) * RB;      // raw image row i
+            const hdem_f4 v = pre[u % PF];
+            const float hv = preh[u % PF];
+            const unsigned g4 = preg[u % PF];
+            *reinterpret_cast<hdem_f4 *>(slot + PADL + 4 * lane) = v;
+            if (has_halo) slot[hidx] = hv;
+            load_row(i + PF, pre[u % PF], preh[u % PF]);
+            preg[u % PF] = load_mask(i + PF);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- 4 + 2p values around my columns ------------------------------------
+            float d[NRD * 4];
+#pragma unroll
+            for (int k = 0; k < NRD; ++k) {
+                const hdem_f4 q = *reinterpret_cast<const hdem_f4 *>(slot + 4 * lane + 4 * k);
+                d[4 * k] = q[0] - c0; d[4 * k + 1] = q[1] - c0;
+                d[4 * k + 2] = q[2] - c0; d[4 * k + 3] = q[3] - c0;
+            }
+            // ---- row sums, then into the ring of vertical accumulators --------------
+            float r0[4], r2[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s0 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WS; ++k) {
+                    s0 += d[OFF + o + k];
+                    s2 = fmaf(d[OFF + o + k], cf.v2[k], s2);
+                }
+                r0[o] = s0;
+                r2[o] = cf.a * s2;
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const f2 r = {r0[2 * p2], r0[2 * p2 + 1]}, t = {r2[2 * p2], r2[2 * p2 + 1]};
+#pragma unroll
+                for (int j = 0; j < WS; ++j) {
+                    // output row (i - j) sits in slot (u - j) mod WS and takes weight cy[j]
+                    const int sl = ((u - j) % WS + WS) % WS;
+                    const f2 cy = {cf.cy[j], cf.cy[j]};
+                    acc[sl][p2] = __builtin_elementwise_fma(cy, r, acc[sl][p2] + t);
+                }
+            }
+            // ---- output row i - 2p is complete: blend and store ------------------------
+            const int done = (u + 1) % WS;            // slot of output row i - (WS - 1)
+            const int oy = i - 2 * P, y = y0 + oy;
+            if (oy >= 0 && oy < SR_ROWS && y < H && x < W) {
+                const size_t gi = (size_t)y * W + x;
+                float o4[4];
+                // the centre row of this output (input row i - p) is still in the ring, raw
+                const hdem_f4 wq = *reinterpret_cast<const hdem_f4 *>(
+                    rb + ((i - P) & (NSLOT - 1)) * RB + PADL + 4 * lane);
+                const float wv[4] = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float smooth = c0 + acc[done][k >> 1][k & 1];
+                    const int xx = x + k;
+                    const bool ring = y < P || y >= H - P || xx < P || xx >= W - P;
+                    float o;
+                    if (ring) {
+                        o = wv[k];
+                    } else if (groves) {
+                        const float hl = wv[k] - smooth;
+                        const bool m = ((g4 >> (8 * k)) & 0xffu) != 0 && hl > thr;
+                        o = m ? smooth : hl + smooth;
+                    } else {
+                        o = smooth;
+                    }
+                    o4[k] = o;
+                }
+                if (vec_ok) {
+                    hdem_f4 q = {o4[0], o4[1], o4[2], o4[3]};
+                    hdem_st4u(out + gi, q);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) out[gi + k] = o4[k];
+                }
+            }
+            acc[done][0] = (f2){0.0f, 0.0f};
+            acc[done][1] = (f2){0.0f, 0.0f};
+        }
+    }
+}
+
 int make_coef(int ws, quad_coef *cf)
 {
     double v[WS_MAX], r0 = (double)ws * ws, r1 = 0, r2 = 0, r3 = 0;
@@ -164,6 +349,13 @@ template <int WS>
 void launch_ws(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, int W,
                float thr, const quad_coef &cf, float *out)
 {
+    if constexpr (WS == 15 || WS == 9 || WS == 3) {      // streaming form (prefetch ring | ws)
+        const int sx = (W + SW_COLS - 1) / SW_COLS, sy = (H + SR_ROWS - 1) / SR_ROWS;
+        const int n = sx * sy;
+        hipLaunchKernelGGL(groves_stream_kernel<WS>, dim3((n + 3) / 4), dim3(NT), 0, ctx->stream,
+                           img, groves, H, W, thr, sx, n, cf, out);
+        return;
+    }
     int tx = (W + GTW - 1) / GTW, ty = (H + GTH - 1) / GTH;
     hipLaunchKernelGGL(groves_kernel<WS>, dim3(tx * ty), dim3(NT), 0, ctx->stream, img,
                        groves, H, W, thr, tx, cf, out);
