@@ -35,10 +35,8 @@
 //     no contended counters -- a single hot atomic costs ~12 ns per arrival and
 //     was measured to dominate everything else here;
 //   * asynchronous driver (the work horse): one persistent launch; a workgroup
-//     keeps relaxing whichever of its queued tiles carries the lowest key (the
-//     lowest elevation a neighbour offered it: flood order, which keeps the
-//     visits per tile low); waking a neighbour is one compare-and-swap on its
-//     state word;
+//     keeps relaxing whichever of its queued tiles was woken first; waking a
+//     neighbour is one compare-and-swap on its state word;
 //   * round-synchronous driver: one launch per round, state word = stamp of the
 //     round the tile is due in, waking is a plain store.  Used behind the
 //     asynchronous launch to certify (or finish) the fixed point, and on its own
@@ -214,8 +212,6 @@ struct visit_result {
     bool changed;      // some interior cell was lowered (the tile was written back)
     bool more;         // still changing at the iteration cap: visit again
     unsigned dirs;     // bit k set: neighbour k (NW,N,NE,W,E,SW,S,SE) can use the new edge
-    int key;           // PER LANE: lane k < 8 holds the lowest value now offered to
-                       // neighbour k (priority key); lane 8 the lowest of the eight
     int iters;
 };
 
@@ -225,7 +221,12 @@ struct visit_result {
 // accesses -- loads bypass L1, stores write through -- so that a tile handed from
 // one workgroup to another inside the launch needs no cache-wide fence
 // (MI355X_MICROARCH.md, "Valid forms").  The round driver uses plain accesses.
-template <bool HAS_EPS, bool COHERENT>
+// W_FIRST (round driver): fetch W alone, and Z only if some cell has a lower
+// neighbour -- otherwise nothing can change whatever Z is.  Halves the traffic of
+// the certifying pass (every visit there is of that kind); the asynchronous driver
+// keeps both loads in flight together, where the extra round trip costs more than
+// the bytes.
+template <bool HAS_EPS, bool COHERENT, bool W_FIRST>
 __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
                                                    int H, int W, float eps, int ty, int tx,
                                                    float *T)
@@ -248,7 +249,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
-        z[r] = zg[o];
+        if (!W_FIRST) z[r] = zg[o];
         // (an agent-scope __hip_atomic_load is waited for one by one -- 64 serial round
         // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
         if (COHERENT)
@@ -256,6 +257,39 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
                 wrsrc, (unsigned)(o * sizeof(float)), 0, AUX_SC1));
         else
             w[r] = wg[o];
+    }
+    if (W_FIRST) {
+        unsigned long long lower = 0;
+        const bool in_x = x < W;
+        auto wall = [&](int r) {                       // nodata / outside: a +inf wall
+            const float v = (in_x && y0 + r < H) ? w[r] : HDEM_INF;
+            return v != v ? HDEM_INF : v;
+        };
+        float a0 = wall(0), a1 = wall(1);
+        float h_prev = fminf(fminf(a0, lane_prev(a0)), lane_next(a0));
+        float h_cur = fminf(fminf(a1, lane_prev(a1)), lane_next(a1));
+#pragma unroll
+        for (int r = 1; r <= WN - 2; ++r) {
+            const float a2 = wall(r + 1);
+            const float h_next = fminf(fminf(a2, lane_prev(a2)), lane_next(a2));
+            float c = fminf(fminf(h_prev, h_cur), h_next);
+            if (HAS_EPS) c = c + eps;
+            or_less(lower, c, a1);
+            a1 = a2;
+            h_prev = h_cur;
+            h_cur = h_next;
+        }
+        // lanes 0 / 63 are halo columns (and their shifted-in neighbour reads 0)
+        if ((lower & (((1ull << FT) - 1) << 1)) == 0) {
+            visit_result none;
+#ifdef HDEM_VISIT_PROF
+            for (int k = 0; k < 6; ++k) none.ticks[k] = 0;
+#endif
+            none.changed = false; none.more = false; none.dirs = 0; none.iters = 0;
+            return none;
+        }
+#pragma unroll
+        for (int r = 0; r < WN; ++r) z[r] = zg[(size_t)min(y0 + r, H - 1) * W + xc];
     }
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
@@ -280,7 +314,6 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
 #endif
     out.dirs = 0;
     out.iters = 0;
-    out.key = KEY_NONE;
     scan_masks V = {0, 0, 0}, Hm = {0, 0, 0};          // cumulative over the visit
     check_rows<HAS_EPS>(z, w, eps, V);
     V.all |= V.first | V.last;
@@ -394,18 +427,6 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
             if (col1_moved && (side & 1ull)) out.dirs |= 1u << 3;                  // W
             if (col62_moved && (side & (1ull << (WN - 1)))) out.dirs |= 1u << 4;   // E
         }
-        float colmin = HDEM_INF;
-#pragma unroll
-        for (int r = 1; r <= FT; ++r) colmin = fminf(colmin, w[r]);
-        const float k_n = wave_min(e1), k_s = wave_min(e62);
-        const float k_w = __shfl(colmin, 1), k_e = __shfl(colmin, FT);
-        const float k_nw = __shfl(w[1], 1), k_ne = __shfl(w[1], FT);
-        const float k_sw = __shfl(w[FT], 1), k_se = __shfl(w[FT], FT);
-        const float k_all = fminf(fminf(k_n, k_s), fminf(k_w, k_e));   // corners lie on the edges
-        const float mine = lane == 0 ? k_nw : lane == 1 ? k_n : lane == 2 ? k_ne
-                         : lane == 3 ? k_w : lane == 4 ? k_e : lane == 5 ? k_sw
-                         : lane == 6 ? k_s : lane == 7 ? k_se : k_all;
-        out.key = float_key(mine);
         PROF_MARK(5);
     }
     out.more = more;
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
             due &= due - 1;
             const int t = slot * G + b;
             const int ty = t / tiles_x, tx = t - ty * tiles_x;
-            const visit_result v = tile_visit<HAS_EPS, false>(zg, wg, H, W, eps, ty, tx, T);
+            const visit_result v = tile_visit<HAS_EPS, false, true>(zg, wg, H, W, eps, ty, tx, T);
             if (lane < 8 && ((v.dirs >> lane) & 1u)) {
                 const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
                 if (t2 >= 0) {
@@ -544,11 +565,39 @@ __device__ __attribute__((noinline)) int async_pick(int b, int G, int S, int nti
         }
         if (best != 0x7fffffffffffffffll) {
             const int slot = (int)(best & 0xffffffffll);
-            if (lane == 0) {
-                atomicExch(&my_prio[slot], KEY_NONE);
-                atomicExch(&my_state[slot], ST_RUNNING);
-            }
+            // claim it (a thief may be after the same tile)
+            int got = 0;
+            if (lane == 0) got = atomicCAS(&my_state[slot], ST_QUEUED, ST_RUNNING) == ST_QUEUED;
+            got = __shfl(got, 0);
+            if (!got) continue;
+            if (lane == 0) atomicExch(&my_prio[slot], KEY_NONE);
             return slot * G + b;
+        }
+        // Nothing of my own is queued: steal.  Ownership only says where a tile's state
+        // word lives; any workgroup may run a queued tile once it has won the CAS.
+        for (int tries = 0; tries < 4; ++tries) {
+            const int victim = (int)((unsigned)(b + 1 + (unsigned)(wall_clock64() >> 3) % (unsigned)G +
+                                                tries * 997u) % (unsigned)G);
+            const int *vs = state + (size_t)victim * S;
+            int found = -1;
+            for (int base = 0; base < S && found < 0; base += NT) {
+                const int slot = base + lane;
+                const bool q = slot < S && slot * G + victim < ntiles &&
+                               ld_relaxed(&vs[slot]) == ST_QUEUED;
+                const unsigned long long m = __ballot(q);
+                if (m) found = base + __builtin_ctzll(m);
+            }
+            if (found >= 0) {
+                int got = 0;
+                if (lane == 0)
+                    got = atomicCAS(&state[(size_t)victim * S + found], ST_QUEUED, ST_RUNNING) ==
+                          ST_QUEUED;
+                got = __shfl(got, 0);
+                if (got) {
+                    if (lane == 0) atomicExch(&prio[(size_t)victim * S + found], KEY_NONE);
+                    return found * G + victim;
+                }
+            }
         }
         // nothing queued here: leave once the whole raster looks drained
         int p = ld_relaxed(&pend[lane * PEND_STRIDE]);
@@ -571,26 +620,30 @@ __device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int 
                                                        int tiles_y, int *state, int *prio,
                                                        int *pend, unsigned long long *stats,
                                                        bool changed, bool more, unsigned dirs,
-                                                       int key, int iters)
+                                                       int iters)
 {
     const int lane = threadIdx.x;
-    const int ty = t / tiles_x, tx = t - ty * tiles_x, slot = t / G;
-    int *my_state = state + (size_t)b * S, *my_prio = prio + (size_t)b * S;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x, slot = t / G, owner = t % G;
+    int *my_state = state + (size_t)owner * S, *my_prio = prio + (size_t)owner * S;
+    // queue order: first come, first served (key = time of the first wake, 100 MHz
+    // ticks).  Flood order (key = lowest elevation offered) was tried and is worse: a
+    // tile woken early and low runs before its other neighbours have spoken.
+    const int now_key = (int)(wall_clock64() & 0x3fffffff);
     // A tile that wakes nobody needs no release: nobody depends on seeing it before
     // the launch ends (its edge cannot lower any neighbour cell).
     if (changed && dirs) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have landed
         if (lane < 8 && ((dirs >> lane) & 1u)) {
             const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
-            if (t2 >= 0) wake_async(t2, key, G, S, state, prio, pend);
+            if (t2 >= 0) wake_async(t2, now_key, G, S, state, prio, pend);
         }
     }
     if (lane == 8) {
-        if (more) atomicMin(&my_prio[slot], key);
+        if (more) atomicMin(&my_prio[slot], now_key);
         const int target = more ? ST_QUEUED : ST_IDLE;
         const int old = atomicCAS(&my_state[slot], ST_RUNNING, target);
         if (old == ST_DIRTY) atomicExch(&my_state[slot], ST_QUEUED);
-        else if (target == ST_IDLE) atomicAdd(pend + (b % PEND_SHARDS) * PEND_STRIDE, -1);
+        else if (target == ST_IDLE) atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, -1);
         add_stats(stats, b, changed, more, iters);
     }
 }
@@ -629,12 +682,12 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         t_mark = now;
         if (t < 0) break;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T);
+        const visit_result v = tile_visit<HAS_EPS, true, false>(zg, wg, H, W, eps, ty, tx, T);
 #ifdef HDEM_VISIT_PROF
         const long long t_v = wall_clock64();
 #endif
         async_finish(t, b, G, S, tiles_x, tiles_y, state, prio, pend, stats, v.changed, v.more,
-                     v.dirs, v.key, v.iters);
+                     v.dirs, v.iters);
         now = wall_clock64();
 #ifdef HDEM_VISIT_PROF
         if (threadIdx.x == 8) {
@@ -652,37 +705,69 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
 }
 
 // W0: pinned cells <- Z (ring, nodata, neighbours of nodata), the rest +inf.
-// One lane per cell; the 3x3 nodata probe is served by L1/L2.  tile_key[t]
-// receives the lowest pinned elevation next to tile t (KEY_NONE: none).
+// One lane per 4 consecutive cells of a row: the three rows around them come in
+// as one 16-byte load plus two edge cells each, the result leaves as one 16-byte
+// store (8 B/cell of HBM traffic).  tile_key[t] receives the lowest pinned
+// elevation next to tile t (KEY_NONE: none); pinned cells are few (ring + nodata
+// fringe), so that atomic is cold.
 __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restrict__ z,
                                                       float *__restrict__ w, int H, int W,
                                                       int tiles_x, int *tile_key,
                                                       int ghost_top, int ghost_bottom)
 {
-    const size_t i = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
-    if (i >= (size_t)H * W) return;
-    const int y = (int)(i / W), x = (int)(i % W);
-    const float zc = z[i];
-    // a ghost row belongs to the neighbouring row block: only its two border
-    // cells are pinned; the rest waits at +inf for the first halo exchange
-    const bool ghost = (ghost_top && y == 0) || (ghost_bottom && y == H - 1);
-    if (ghost && x != 0 && x != W - 1) { w[i] = zc != zc ? zc : HDEM_INF; return; }
-    bool pin = y == 0 || y == H - 1 || x == 0 || x == W - 1 || zc != zc;
-    if (!pin) {
+    const int quads = (W + 3) / 4;
+    const size_t q = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
+    if (q >= (size_t)H * quads) return;
+    const int y = (int)(q / quads), x = (int)(q % quads) * 4;
+    // rows y-1, y, y+1, columns x-1 .. x+4 (clamped: a clamped duplicate cannot add a NaN
+    // that is not already in the neighbourhood)
+    float v[3][6];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+    for (int r = 0; r < 3; ++r) {
+        const float *row = z + (size_t)min(max(y + r - 1, 0), H - 1) * W;
+        v[r][0] = row[max(x - 1, 0)];
+        if (x + 4 <= W) {
+            const hdem_f4 m = hdem_ld4u(row + x);
+            v[r][1] = m[0]; v[r][2] = m[1]; v[r][3] = m[2]; v[r][4] = m[3];
+        } else {
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const float zn = z[(size_t)(y + dy) * W + (x + dx)];
-                pin |= zn != zn;   // a nodata cell in a ghost row is nodata for its owner too
-            }
+            for (int k = 0; k < 4; ++k) v[r][1 + k] = row[min(x + k, W - 1)];
+        }
+        v[r][5] = row[min(x + 4, W - 1)];
     }
-    w[i] = pin ? zc : HDEM_INF;
-    if (pin && zc == zc && tiles_x > 0) {
-        // the tile whose interior is nearest (ring cells belong to no interior);
-        // pinned cells are few (ring + nodata fringe), so this atomic is cold
-        const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(x - 1, 0), W - 3) / FT;
-        atomicMin(&tile_key[ty * tiles_x + tx], float_key(zc));
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = x + k;
+        const float zc = v[1][1 + k];
+        // a ghost row belongs to the neighbouring row block: only its two border
+        // cells are pinned; the rest waits at +inf for the first halo exchange
+        const bool ghost = ((ghost_top && y == 0) || (ghost_bottom && y == H - 1)) &&
+                           xx != 0 && xx != W - 1;
+        bool pin = y == 0 || y == H - 1 || xx == 0 || xx >= W - 1 || zc != zc;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pin |= v[r][k + c] != v[r][k + c];
+        if (ghost) {
+            o[k] = zc != zc ? zc : HDEM_INF;
+        } else {
+            o[k] = pin ? zc : HDEM_INF;
+            if (pin && zc == zc && tiles_x > 0 && xx < W) {
+                // the tile whose interior is nearest (ring cells belong to no interior)
+                const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
+                atomicMin(&tile_key[ty * tiles_x + tx], float_key(zc));
+            }
+        }
+    }
+    float *dst = w + (size_t)y * W + x;
+    if (x + 4 <= W) {
+        const hdem_f4 m = {o[0], o[1], o[2], o[3]};
+        hdem_st4u(dst, m);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x + k < W) dst[k] = o[k];
     }
 }
 
@@ -714,7 +799,7 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
     if (key == KEY_NONE) return;
     const int owner = t % G, idx = owner * S + t / G;
     if (async) {
-        prio[idx] = key;
+        prio[idx] = 0;                                  // seeds go first (queue order: oldest)
         state[idx] = ST_QUEUED;
         // 64 shards and one arrival per tile: ~1k arrivals per shard at 16384^2, once
         atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
@@ -804,7 +889,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
 
     if (!warm) {
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
-        const size_t n = (size_t)H * W;
+        const size_t n = (size_t)H * ((W + 3) / 4);
         hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
                            dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
                            flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);

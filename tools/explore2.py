@@ -15,5 +15,5 @@ for rep in range(3):
     t = time.time()
     _, st = B.sinkfill_dev(zd, out=wd, flags=B.FILL_WARM | B.FILL_SYNC_ONLY)
     ctx.synchronize(); dt = time.time() - t
-    k = ctx.profile_get(B.K_FILL_TILE)
+    k = ctx.profile_get(B.K_FILL_ROUND)
     print(f"verify-only pass: wall {dt*1e3:.3f} ms kernel {k['ms']:.3f} ms launches {k['launches']} visits {st['tile_visits']} -> {k['ms']*1e3*2048/max(st['tile_visits'],1):.2f} us per visit-slot; GB/s (8B/cell) {8*n*n/k['ms']/1e6:.0f}")
