@@ -221,12 +221,7 @@ struct visit_result {
 // accesses -- loads bypass L1, stores write through -- so that a tile handed from
 // one workgroup to another inside the launch needs no cache-wide fence
 // (MI355X_MICROARCH.md, "Valid forms").  The round driver uses plain accesses.
-// W_FIRST (round driver): fetch W alone, and Z only if some cell has a lower
-// neighbour -- otherwise nothing can change whatever Z is.  Halves the traffic of
-// the certifying pass (every visit there is of that kind); the asynchronous driver
-// keeps both loads in flight together, where the extra round trip costs more than
-// the bytes.
-template <bool HAS_EPS, bool COHERENT, bool W_FIRST>
+template <bool HAS_EPS, bool COHERENT>
 __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
                                                    int H, int W, float eps, int ty, int tx,
                                                    float *T)
@@ -249,7 +244,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
-        if (!W_FIRST) z[r] = zg[o];
+        z[r] = zg[o];
         // (an agent-scope __hip_atomic_load is waited for one by one -- 64 serial round
         // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
         if (COHERENT)
@@ -257,39 +252,6 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
                 wrsrc, (unsigned)(o * sizeof(float)), 0, AUX_SC1));
         else
             w[r] = wg[o];
-    }
-    if (W_FIRST) {
-        unsigned long long lower = 0;
-        const bool in_x = x < W;
-        auto wall = [&](int r) {                       // nodata / outside: a +inf wall
-            const float v = (in_x && y0 + r < H) ? w[r] : HDEM_INF;
-            return v != v ? HDEM_INF : v;
-        };
-        float a0 = wall(0), a1 = wall(1);
-        float h_prev = fminf(fminf(a0, lane_prev(a0)), lane_next(a0));
-        float h_cur = fminf(fminf(a1, lane_prev(a1)), lane_next(a1));
-#pragma unroll
-        for (int r = 1; r <= WN - 2; ++r) {
-            const float a2 = wall(r + 1);
-            const float h_next = fminf(fminf(a2, lane_prev(a2)), lane_next(a2));
-            float c = fminf(fminf(h_prev, h_cur), h_next);
-            if (HAS_EPS) c = c + eps;
-            or_less(lower, c, a1);
-            a1 = a2;
-            h_prev = h_cur;
-            h_cur = h_next;
-        }
-        // lanes 0 / 63 are halo columns (and their shifted-in neighbour reads 0)
-        if ((lower & (((1ull << FT) - 1) << 1)) == 0) {
-            visit_result none;
-#ifdef HDEM_VISIT_PROF
-            for (int k = 0; k < 6; ++k) none.ticks[k] = 0;
-#endif
-            none.changed = false; none.more = false; none.dirs = 0; none.iters = 0;
-            return none;
-        }
-#pragma unroll
-        for (int r = 0; r < WN; ++r) z[r] = zg[(size_t)min(y0 + r, H - 1) * W + xc];
     }
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
@@ -479,7 +441,7 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
             due &= due - 1;
             const int t = slot * G + b;
             const int ty = t / tiles_x, tx = t - ty * tiles_x;
-            const visit_result v = tile_visit<HAS_EPS, false, true>(zg, wg, H, W, eps, ty, tx, T);
+            const visit_result v = tile_visit<HAS_EPS, false>(zg, wg, H, W, eps, ty, tx, T);
             if (lane < 8 && ((v.dirs >> lane) & 1u)) {
                 const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
                 if (t2 >= 0) {
@@ -682,7 +644,7 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         t_mark = now;
         if (t < 0) break;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const visit_result v = tile_visit<HAS_EPS, true, false>(zg, wg, H, W, eps, ty, tx, T);
+        const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T);
 #ifdef HDEM_VISIT_PROF
         const long long t_v = wall_clock64();
 #endif
