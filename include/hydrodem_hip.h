@@ -97,8 +97,10 @@ typedef struct hdem_fill_stats {
     int64_t tile_visits;      /* tile visits, both drivers                     */
     int64_t tiles;            /* tiles in the raster                         */
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
-    int32_t scans;            /* directional scan launches                   */
-    int32_t async_timed_out;  /* 1: the asynchronous launch hit its wall-clock budget  */
+    int32_t scans;            /* (reserved, 0)                               */
+    int32_t async_timed_out;  /* != 0: the asynchronous launch gave up (1 wall-clock
+                                 budget, 2 workgroups not co-resident); the round driver
+                                 finished the fill                              */
     int64_t iterations;       /* 4-scan iterations, summed over tile visits  */
     int64_t visits_unchanged; /* visits that found nothing to lower          */
     int64_t visits_requeued;  /* visits that hit the iteration cap           */

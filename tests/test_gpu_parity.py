@@ -398,3 +398,57 @@ def test_virtual_rank_partition_on_hip(world, H, W):
         codes.append(d[P.owned_slice(r, world)].cpu().numpy())
     assert np.array_equal(np.concatenate(codes), c_oracle.d8(want))
     solver.ctx.set_stream(None)
+
+
+# --------------------------------------------------------------------------
+# C-ABI error behaviour (status codes + hdem_last_error), straight through ctypes
+# --------------------------------------------------------------------------
+def test_c_abi_error_codes():
+    import ctypes
+    lib = backend.load_library()
+    ctx = backend.context()
+    z = oracle.synth_dem(32, 40)
+    out = np.empty_like(z)
+    zp, op = z.ctypes.data, out.ctypes.data
+    msg = lambda: lib.hdem_last_error().decode()
+    assert lib.hdem_d8_f32(ctx.handle, None, 32, 40, op) == backend.BAD_ARG and "null" in msg()
+    assert lib.hdem_d8_f32(ctx.handle, zp, 0, 40, op) == backend.BAD_ARG and "positive" in msg()
+    assert lib.hdem_sinkfill_f32(ctx.handle, zp, 32, 40, ctypes.c_float(-1.0), 0, op, None) == backend.BAD_ARG
+    assert "eps" in msg()
+    assert lib.hdem_quadratic_f32(ctx.handle, zp, 32, 40, 4, op) == backend.WINDOW_EVEN
+    assert msg() == "Window size: 4 cannot be an even number"
+    assert lib.hdem_quadratic_f32(ctx.handle, zp, 32, 40, 33, op) == backend.WINDOW_HIGH
+    assert msg() == "Window size: 33 cannot be higher than grid dimensions: (32, 40)"
+    assert lib.hdem_groves_f32(ctx.handle, zp, None, 32, 40, 15, ctypes.c_float(1.5), 1, op) == backend.BAD_ARG
+    g = np.zeros(z.shape, np.uint8)
+    assert lib.hdem_groves_f32(ctx.handle, zp, g.ctypes.data, 32, 40, 15, ctypes.c_float(1.5), 0, op) == backend.BAD_ARG
+    w = np.ones((2, 3))
+    assert lib.hdem_convolve_f32(ctx.handle, zp, 32, 40, w.ctypes.data, 2, 3, op) == backend.WINDOW_EVEN
+    n = ctypes.c_int(0)
+    assert lib.hdem_device_count(ctypes.byref(n)) == 0 and n.value >= 1
+    bad = ctypes.c_void_p()
+    assert lib.hdem_init(99, ctypes.byref(bad)) == backend.BAD_ARG and not bad.value
+    # device-pointer variants refuse to run in place
+    with backend.DeviceRaster.from_host(z) as zd:
+        assert lib.hdem_sinkfill_f32_dev(ctx.handle, zd.ptr, 32, 40, ctypes.c_float(0), 0, 0, zd.ptr, None) \
+            == backend.BAD_ARG and "in place" in msg()
+        assert lib.hdem_boxmean3_f32_dev(ctx.handle, zd.ptr, 32, 40, 1, zd.ptr) == backend.BAD_ARG
+    # a round limit that is too small is reported, not hidden
+    big = oracle.synth_dem(700, 700)
+    with backend.DeviceRaster.from_host(big) as bd:
+        with pytest.raises(hd.NotConvergedError):
+            backend.sinkfill_dev(bd, max_rounds=2, flags=backend.FILL_SYNC_ONLY)[0].free()
+
+
+def test_degenerate_rasters():
+    for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (2, 9), (3, 3)]:
+        z = oracle.synth_dem(*shape)
+        w = hd.SinkFill().apply(z)
+        want, _ = oracle.sinkfill_jacobi(z)
+        assert np.array_equal(w, want), shape
+        assert np.array_equal(hd.PostProcessingFinal().apply(z), c_oracle.boxmean3(z, True))
+    z = np.full((40, 40), 7.0, np.float32)               # one big flat
+    assert np.array_equal(hd.SinkFill().apply(z), z)
+    assert not hd.D8FlowDirection().apply(z).any()
+    z = np.full((70, 70), np.nan, np.float32)             # all nodata
+    assert np.isnan(hd.SinkFill().apply(z)).all()

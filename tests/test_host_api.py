@@ -158,3 +158,27 @@ def test_dropin_directory_resolves_flat_imports():
         "print('ok')\n") % (ROOT, os.path.join(ROOT, "hydrodem_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_python_constants_match_the_header():
+    header = open(os.path.join(ROOT, "include", "hydrodem_hip.h")).read()
+    defines = {m.group(1): int(m.group(2), 0)
+               for m in re.finditer(r"#define\s+(HDEM_FILL_[A-Z_]+)\s+(0x[0-9a-fA-F]+|\d+)", header)}
+    assert defines["HDEM_FILL_WARM"] == backend.FILL_WARM
+    assert defines["HDEM_FILL_ACT_TOP"] == backend.FILL_ACT_TOP
+    assert defines["HDEM_FILL_ACT_BOTTOM"] == backend.FILL_ACT_BOTTOM
+    assert defines["HDEM_FILL_GHOST_TOP"] == backend.FILL_GHOST_TOP
+    assert defines["HDEM_FILL_GHOST_BOTTOM"] == backend.FILL_GHOST_BOTTOM
+    assert defines["HDEM_FILL_SYNC_ONLY"] == backend.FILL_SYNC_ONLY
+    assert defines["HDEM_FILL_NO_VERIFY"] == backend.FILL_NO_VERIFY
+    enums = dict(re.findall(r"\b(HDEM_(?:K|ERR)_[A-Z0-9_]+|HDEM_OK)\s*=\s*(\d+)", header))
+    assert int(enums["HDEM_K_FILL_TILE"]) == backend.K_FILL_TILE
+    assert int(enums["HDEM_K_FILL_ROUND"]) == backend.K_FILL_ROUND
+    assert int(enums["HDEM_K_GROVES"]) == backend.K_GROVES
+    assert int(enums["HDEM_ERR_WINDOW_EVEN"]) == backend.WINDOW_EVEN
+    assert int(enums["HDEM_ERR_WINDOW_HIGH"]) == backend.WINDOW_HIGH
+    assert int(enums["HDEM_ERR_NOT_CONVERGED"]) == backend.NOT_CONVERGED
+    # struct layouts the binding mirrors
+    # struct layouts the binding mirrors: 6 int32 + 6 int64 / 2 int64 + 1 double
+    assert ctypes.sizeof(backend.FillStats) == 72 and backend.FillStats.round_visits.offset == 64
+    assert ctypes.sizeof(backend.KernelStat) == 24
