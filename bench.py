@@ -47,6 +47,26 @@ def parse():
     return p.parse_args()
 
 
+def profiled_traffic(kernel_substring):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this
+    same command (profiles/r01_bench_pmc_*.csv; FETCH_SIZE and WRITE_SIZE need separate
+    passes and cannot be collected from inside this process).  FETCH_SIZE under-reports
+    on gfx950: x1.605 is the factor measured on a kernel with the same 4-byte-per-lane
+    row loads that reads a known 1.0737 GB.  None when no profile exists."""
+    import csv
+    out = {}
+    for key, name in (("fetch", "r01_bench_pmc_fetch_size.csv"), ("write", "r01_bench_pmc_write_size.csv")):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if kernel_substring in row["Kernel_Name"]:
+                out[key] = float(row["Per_Dispatch"]) * 1024.0
+    if "fetch" not in out or "write" not in out:
+        return None
+    return out["fetch"] * 1.605 + out["write"]
+
+
 def cpu_baseline(z_crop):
     """NumPy oracle (the 'NumPy CPU reference' of north_star) on a crop of the
     workload; checker code timed as a baseline, never used as product."""
@@ -186,7 +206,12 @@ def main():
                        "halo_exchanges": info.get("exchanges", 0)},
             "roofline": {"bound": "hbm", "kernel": "fill_async_kernel",
                          "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fill_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": fill_gbs / HBM_PEAK_GBS,
+                         "traffic": profiled_traffic("fill_async_kernel")
+                         if (N == 1 and S == 16384) else None,
+                         "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.csv: separate "
+                                           "rocprofv3 --pmc passes of this command, bytes per launch, "
+                                           "FETCH_SIZE x1.605 (gfx950 calibration)",
                          "launches": kt["launches"], "ms_total": kt["ms"],
                          "bytes_per_launch": FILL_BYTES_PER_CELL * kt["units"]
                          / max(kt["launches"], 1),
