@@ -8,7 +8,9 @@ a GPU is missing every operator raises :class:`BackendError`.
 """
 
 import ctypes
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -24,9 +26,11 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 
 # kernel ids for the timing query
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
+K_BLOCKMAX = 8
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
+FILL_RESUME, FILL_GHOST_GIVEN = 0x100, 0x200
 
 
 class KernelStat(ctypes.Structure):
@@ -40,7 +44,8 @@ class FillStats(ctypes.Structure):
                 ("tile_h", ctypes.c_int32), ("tile_w", ctypes.c_int32),
                 ("scans", ctypes.c_int32), ("async_timed_out", ctypes.c_int32),
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
-                ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64)]
+                ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64),
+                ("pending", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -55,6 +60,7 @@ SIGNATURES = {
     "hdem_shutdown": [_vp],
     "hdem_set_stream": [_vp, _vp],
     "hdem_synchronize": [_vp],
+    "hdem_set_fill_slice_us": [_vp, _i],
     "hdem_malloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
     "hdem_free": [_vp, _vp],
     "hdem_memcpy_h2d": [_vp, _vp, _vp, _c.c_size_t],
@@ -68,6 +74,7 @@ SIGNATURES = {
     "hdem_sinkfill_f32": [_vp, _vp, _i, _i, _f, _i, _vp, _c.POINTER(FillStats)],
     "hdem_sinkfill_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp,
                               _c.POINTER(FillStats)],
+    "hdem_blockmax_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f32": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f64": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
@@ -86,12 +93,37 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    ``libamdhip64.so`` (soname ``libamdhip64.so.7``, same as ``/opt/rocm``'s) and look
+    it up by file name, so if this library pulled in the system runtime first, a later
+    ``import torch`` would load a second runtime and report no usable GPU.  Loading
+    torch's copy first (without importing torch) makes both bind to the same one.
+    ``HYDRODEM_HIP_RUNTIME=system`` keeps the system runtime (processes that never
+    import torch)."""
+    if os.environ.get("HYDRODEM_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for base in (spec.submodule_search_locations or []) if spec else []:
+        cand = os.path.join(base, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library(path=None):
     """dlopen the HIP library and declare every prototype.  Needs no GPU."""
     global _lib
     with _lock:
         if _lib is not None and path is None:
             return _lib
+        _share_torch_hip_runtime()
         p = path or os.environ.get("HYDRODEM_HIP_LIB", LIB_PATH)
         if not os.path.exists(p):
             raise BackendError(
@@ -153,6 +185,10 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.hdem_synchronize(self.handle))
+
+    def set_fill_slice_us(self, microseconds):
+        """Time slice of the asynchronous sink-fill phase (0 = to convergence)."""
+        self.check(self.lib.hdem_set_fill_slice_us(self.handle, int(microseconds)))
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.hdem_set_stream(self.handle,
@@ -291,6 +327,17 @@ def sinkfill_dev(z, eps=0.0, max_rounds=0, out=None, flags=FILL_INIT):
                                         float(eps), int(max_rounds), int(flags),
                                         out.ptr, ctypes.byref(st)))
     return out, st.as_dict()
+
+
+def blockmax_dev(z, block, out=None):
+    """Block-maximum coarsening (``hdem_blockmax_f32_dev``)."""
+    _need(z, np.float32)
+    shape = (-(-z.shape[0] // block), -(-z.shape[1] // block))
+    out = out or DeviceRaster.empty(shape, np.float32, z.ctx)
+    c = z.ctx
+    c.check(c.lib.hdem_blockmax_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], int(block),
+                                        out.ptr))
+    return out
 
 
 def boxmean3_dev(x, do_round=True, out=None):

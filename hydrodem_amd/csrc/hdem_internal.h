@@ -49,6 +49,11 @@ struct hdem_ctx {
     // sink-fill workspace (grown on demand, reused across calls)
     void *fill_ws = nullptr;
     size_t fill_ws_bytes = 0;
+    int fill_slice_us = 0;             // 0: run the asynchronous phase to convergence
+    int fill_last_h = 0, fill_last_w = 0;   // problem the worklist in fill_ws belongs to
+    const void *fill_last_z = nullptr, *fill_last_out = nullptr;
+    bool fill_resumable = false;       // state words hold a consistent asynchronous worklist
+    bool fill_quiescent = false;       // ... and the last call left nothing to do
     int32_t *host_counts = nullptr;    // pinned: convergence counters
     size_t host_counts_len = 0;
 };

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
                                                           int S, int *state, int *prio,
                                                           int *pend, int *error,
                                                           unsigned long long *stats,
-                                                          long long budget_ticks)
+                                                          long long budget_ticks, int soft)
 {
     __shared__ float T[WN * TS];
     const int G = gridDim.x, b = blockIdx.x;
@@ -637,8 +637,11 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
     for (;;) {
         // readfirstlane: the tile index is wave-uniform; say so, or every row address
         // of the visit is computed (and kept) per lane
+        // soft budget = time slice: just stop taking tiles, everything stays consistent
+        if (soft && wall_clock64() - t_begin > budget_ticks) break;
         const int t = __builtin_amdgcn_readfirstlane(
-            async_pick(b, G, S, ntiles, state, prio, pend, error, t_begin, budget_ticks));
+            async_pick(b, G, S, ntiles, state, prio, pend, soft ? error + 2 : error, t_begin,
+                       budget_ticks));
         long long now = wall_clock64();
         idle += now - t_mark;
         t_mark = now;
@@ -675,7 +678,8 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
 __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restrict__ z,
                                                       float *__restrict__ w, int H, int W,
                                                       int tiles_x, int *tile_key,
-                                                      int ghost_top, int ghost_bottom)
+                                                      int ghost_top, int ghost_bottom,
+                                                      int ghost_given)
 {
     const int quads = (W + 3) / 4;
     const size_t q = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
@@ -711,7 +715,16 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) pin |= v[r][k + c] != v[r][k + c];
-        if (ghost) {
+        if (ghost && ghost_given) {
+            // the caller's upper bound: acts like a pinned cell until the first exchange
+            // (never below the terrain, whatever the caller wrote)
+            const float g = xx < W ? w[(size_t)y * W + xx] : zc;
+            o[k] = zc != zc ? zc : fmaxf(g, zc);
+            if (zc == zc && g == g && tiles_x > 0 && xx < W) {
+                const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
+                atomicMin(&tile_key[ty * tiles_x + tx], float_key(o[k]));
+            }
+        } else if (ghost) {
             o[k] = zc != zc ? zc : HDEM_INF;
         } else {
             o[k] = pin ? zc : HDEM_INF;
@@ -761,17 +774,19 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
     if (key == KEY_NONE) return;
     const int owner = t % G, idx = owner * S + t / G;
     if (async) {
-        prio[idx] = 0;                                  // seeds go first (queue order: oldest)
-        state[idx] = ST_QUEUED;
-        // 64 shards and one arrival per tile: ~1k arrivals per shard at 16384^2, once
-        atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
+        // (works on a fresh worklist and on one resumed from the previous slice)
+        if (atomicCAS(&state[idx], ST_IDLE, ST_QUEUED) == ST_IDLE) {
+            prio[idx] = 0;                              // seeds go first (queue order: oldest)
+            // 64 shards and one arrival per tile: ~1k arrivals per shard at 16384^2, once
+            atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
+        }
     } else {
         state[idx] = stamp;
         *any0 = 1;
     }
 }
 
-int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, fill_ws *ws)
+int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, fill_ws *ws)
 {
     // tiles cover the interior (rows 1..H-2, cols 1..W-2); none if there is no interior
     ws->tiles_x = W >= 3 && H >= 3 ? (W - 2 + FT - 1) / FT : 0;
@@ -795,8 +810,10 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, fill_ws *ws)
         }
         HDEM_HIP_CHECK(hipMalloc(&ctx->fill_ws, bytes));
         ctx->fill_ws_bytes = bytes;
+        *resume = false;                                           // the worklist went with it
     }
-    const size_t host_ints = std::max(stat_ints, (size_t)max_rounds + 32);
+    const size_t host_ints = std::max(std::max(stat_ints, (size_t)max_rounds + 32),
+                                       (size_t)PEND_SHARDS * PEND_STRIDE);
     if (ctx->host_counts_len < host_ints) {
         if (ctx->host_counts) HDEM_HIP_CHECK(hipHostFree(ctx->host_counts));
         ctx->host_counts = nullptr;
@@ -811,13 +828,15 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, fill_ws *ws)
     ws->state = ws->tile_key + n;
     ws->prio = ws->state + gs;
     ws->any = ws->prio + gs;
-    // error, stats, pend = 0; tile_key / prio = "none"; state = IDLE; any = 0
-    HDEM_HIP_CHECK(hipMemsetAsync(base, 0,
-                                  (head + stat_ints + PEND_SHARDS * PEND_STRIDE) * sizeof(int),
-                                  ctx->stream));
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->tile_key, 0x7f, n * sizeof(int), ctx->stream));
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->state, 0, gs * sizeof(int), ctx->stream));
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->prio, 0x7f, gs * sizeof(int), ctx->stream));
+    // error, stats = 0; a resumed worklist keeps pend / state / prio of the last slice
+    HDEM_HIP_CHECK(hipMemsetAsync(base, 0, (head + stat_ints) * sizeof(int), ctx->stream));
+    if (!*resume) {
+        HDEM_HIP_CHECK(hipMemsetAsync(ws->pend, 0, PEND_SHARDS * PEND_STRIDE * sizeof(int),
+                                      ctx->stream));
+        HDEM_HIP_CHECK(hipMemsetAsync(ws->tile_key, 0x7f, n * sizeof(int), ctx->stream));
+        HDEM_HIP_CHECK(hipMemsetAsync(ws->state, 0, gs * sizeof(int), ctx->stream));
+        HDEM_HIP_CHECK(hipMemsetAsync(ws->prio, 0x7f, gs * sizeof(int), ctx->stream));
+    }
     HDEM_HIP_CHECK(hipMemsetAsync(ws->any, 0, ((size_t)max_rounds + 32) * sizeof(int),
                                   ctx->stream));
     return HDEM_OK;
@@ -842,39 +861,64 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                            (size_t)H * W * sizeof(float) < (size_t)0xffffffffu;
     const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
 
+    // a worklist can only be resumed for the problem it was built for; when it cannot,
+    // every tile is due again (correct, just slower)
+    const bool want_resume = (flags & HDEM_FILL_RESUME) && (flags & HDEM_FILL_WARM);
+    const bool same = ctx->fill_last_h == H && ctx->fill_last_w == W && ctx->fill_last_z == z &&
+                      ctx->fill_last_out == w;
+    bool resume = want_resume && use_async && same && ctx->fill_resumable;
+    if (want_resume) flags |= HDEM_FILL_NO_VERIFY;
     fill_ws ws;
-    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * 8, &ws)) return rc;
+    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * 8, &resume, &ws)) return rc;
+    // not resumable: fine if the last call on this problem left nothing queued (then the ACT
+    // flags describe all there is to do), otherwise every tile is due again
+    if (want_resume && !resume && !(same && ctx->fill_quiescent))
+        flags &= ~(HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM);
+    ctx->fill_last_h = H;
+    ctx->fill_last_w = W;
+    ctx->fill_last_z = z;
+    ctx->fill_last_out = w;
+    ctx->fill_resumable = ctx->fill_quiescent = false;   // until this call has ended well
     hipStream_t st = ctx->stream;
     const unsigned tile_blocks = (unsigned)std::max(1, (ws.ntiles + INIT_NT - 1) / INIT_NT);
     const bool warm = (flags & HDEM_FILL_WARM) != 0;
-    const int mode = warm ? (flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM)) : -1;
+    int mode = warm ? (flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM)) : -1;
+    // resuming with no replaced ghost row: nothing to add to the worklist (mode 0 would
+    // mean "all tiles")
+    const bool seed_async = !(resume && mode == 0);
+    const int slice_us = (flags & HDEM_FILL_NO_VERIFY) ? ctx->fill_slice_us : 0;
+    int64_t pending = 0;
 
     if (!warm) {
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
         const size_t n = (size_t)H * ((W + 3) / 4);
         hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
                            dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
-                           flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);
+                           flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM,
+                           flags & HDEM_FILL_GHOST_GIVEN);
     }
     int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
     const bool did_async = use_async && ws.ntiles > 0;
     if (did_async) {
         // ---- asynchronous phase: does (nearly) all of the work -------------------
-        hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
-                           ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1, ws.state,
-                           ws.prio, ws.pend, 0, ws.any);
+        if (seed_async)
+            hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
+                               ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1,
+                               ws.state, ws.prio, ws.pend, 0, ws.any);
         // wall-clock budget (100 MHz ticks): generous against the ~0.15 us per tile a
-        // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second
-        const long long budget = 20000000ll + (long long)ws.ntiles * 200ll;
+        // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second;
+        // or the caller's time slice (soft: the launch just stops taking tiles)
+        const long long budget = slice_us > 0 ? (long long)slice_us * 100ll
+                                              : 20000000ll + (long long)ws.ntiles * 200ll;
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
         if (eps != 0.0f)
             hipLaunchKernelGGL(fill_async_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H, W,
                                eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state, ws.prio,
-                               ws.pend, ws.error, ws.stats, budget);
+                               ws.pend, ws.error, ws.stats, budget, slice_us > 0);
         else
             hipLaunchKernelGGL(fill_async_kernel<false>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
@@ -882,10 +926,18 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // on its own it starts from the same seeds
     bool verify = !(did_async && (flags & HDEM_FILL_NO_VERIFY));
     if (!verify) {
-        // trust the asynchronous phase unless it ran out of its wall-clock budget
+        // trust the asynchronous phase unless it gave up; after a time slice, report how
+        // many tiles are still queued (the worklist stays in the workspace for RESUME)
         HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (slice_us > 0)
+            HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.pend,
+                                          PEND_SHARDS * PEND_STRIDE * sizeof(int),
+                                          hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
-        if (async_error) verify = true; else converged = 1;
+        if (slice_us > 0)
+            for (int i = 0; i < PEND_SHARDS; ++i) pending += ctx->host_counts[i * PEND_STRIDE];
+        if (async_error) { verify = true; pending = 0; }
+        else converged = pending == 0;
     }
     if (ws.ntiles > 0 && verify)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
@@ -953,10 +1005,22 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         stats->visits_requeued = (int64_t)tot[3];
         stats->round_visits = (int64_t)tot[6];
     }
-    if (!converged) {
+    if (stats) stats->pending = pending;
+    if (!converged && pending == 0) {
         hdem_set_error("sink fill did not converge in %d rounds", max_rounds);
         return HDEM_ERR_NOT_CONVERGED;
     }
+    // the round driver leaves round stamps in the state words: no worklist to resume
+    ctx->fill_resumable = did_async && !verify;
+    ctx->fill_quiescent = converged != 0;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_set_fill_slice_us(hdem_ctx *ctx, int microseconds)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    HDEM_REQUIRE(microseconds >= 0, HDEM_ERR_BAD_ARG, "slice must be >= 0 us");
+    ctx->fill_slice_us = microseconds;
     return HDEM_OK;
 }
 

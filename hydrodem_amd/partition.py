@@ -11,16 +11,32 @@ The first and last row of every local array are therefore the Dirichlet ring
 of the local problem -- the raster border on the outer ranks, a ghost row
 elsewhere -- which is exactly what the single-GPU solver pins.
 
-Sink fill.  repeat { relax the local block to its fixed point with the ghost
-rows frozen ; swap boundary rows with rank+-1 (point-to-point, W*4 bytes each
-way) ; all-reduce one "any ghost row changed" flag } until the flag is clear;
+Sink fill.  repeat { relax the local block with the ghost rows frozen, for one
+time slice or to its fixed point, whichever comes first ; swap boundary rows
+with rank+-1 (point-to-point, W*4 bytes each way) ; all-reduce one "a ghost row
+changed or tiles are still queued somewhere" flag } until the flag is clear;
 then every rank runs one verifying pass over its whole block (the intermediate
 solves skip it) and the loop resumes only if that pass lowered something.
+(The time slice is optional, ``DEFAULT_SLICE_US``: with good start values for the
+ghost rows -- next paragraph -- solving to the local fixed point between exchanges
+is the faster schedule.)
 Legal for any interleaving because the relaxation is monotone from above
 (stale ghost rows are upper bounds: they delay, never corrupt), and the state
 at exit is a fixed point of the global operator, hence the same bits as the
 single-GPU result.  D8 needs the ghost rows of the filled surface, which the
 last exchange leaves in place.
+
+Start values of the ghost rows.  A rank that starts with its ghost rows at +inf
+first fills against two walls and redoes most of that when the neighbours' real
+rows arrive (measured: 2.3x the tile visits of an undivided raster).  So the
+ranks first solve the *whole* raster on a coarse grid: each takes block maxima
+of its owned rows (``COARSE_BLOCK`` x ``COARSE_BLOCK`` cells, NaN -> wall),
+all-gathers them (W*H/b^2 floats in total) and fills the stacked coarse raster
+-- redundantly, it is tiny.  A fine path that stays inside a chain of adjacent
+blocks never exceeds the chain's maxima, so the coarse fill bounds the fine
+fill from above, which is all a start value has to satisfy; the ghost rows
+start at the coarse level of their block.  Only for epsilon = 0 (with a
+gradient the bound would need the path length).
 
 The local solver is injected (``solver=``): the HIP backend on GPUs; the CPU
 tests pass a NumPy solver so that this exchange logic runs under ``gloo``.
@@ -46,29 +62,57 @@ def local_range(rank, world, total_rows):
     return r0 - int(top), r1 + int(bottom), top, bottom
 
 
+# Time slice of the intermediate solves in microseconds; 0 = every solve runs to its local
+# fixed point.  Slicing lets blocks trade rows while both still relax, which pays when
+# the ghost rows start far from the truth (+inf: 26 -> 23 ms predicted at 4 x 16384^2);
+# behind the coarse pre-solve the start values are good and the extra exchanges cost
+# more than they save (17.3 ms unsliced, 18.9 ms with 2.5 ms slices), so it is off.
+DEFAULT_SLICE_US = 0
+# Edge of the blocks of the coarse pre-solve (power of two, 4..256).
+COARSE_BLOCK = 32
+
+
 class HipLocalSolver:
     """Local block solver on the HIP backend; tensors are CUDA torch tensors
     whose memory the kernels use in place (no copies)."""
 
-    def __init__(self, device_index=None):
+    def __init__(self, device_index=None, slice_us=DEFAULT_SLICE_US, own_context=False):
         import torch
         self.torch = torch
-        self.ctx = backend.context(torch.cuda.current_device()
-                                   if device_index is None else device_index)
+        device_index = torch.cuda.current_device() if device_index is None else device_index
+        # the worklist of a time-sliced solve lives in the context: one context per block
+        # (own_context) when several blocks are solved in one process
+        self.ctx = backend.Context(device_index) if own_context else backend.context(device_index)
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.slice_us = slice_us
 
     def _wrap(self, t, dtype):
         return backend.DeviceRaster.wrap(t.data_ptr(), tuple(t.shape), dtype,
                                          ctx=self.ctx, keepalive=t)
 
-    def fill(self, z, w, eps, flags):
-        """Returns (tile visits, whether any cell was lowered)."""
-        _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
-                                     out=self._wrap(w, np.float32), flags=flags)
-        return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"]
+    def fill(self, z, w, eps, flags, sliced=False):
+        """Returns (tile visits, whether any cell was lowered, tiles still queued).
+        ``sliced``: stop after ``slice_us`` even if tiles are still queued (only
+        honoured together with FILL_NO_VERIFY)."""
+        sliced = bool(sliced and self.slice_us > 0)
+        self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
+        try:
+            _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
+                                         out=self._wrap(w, np.float32), flags=flags)
+        finally:
+            self.ctx.set_fill_slice_us(0)
+        return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"], st["pending"]
 
     def d8(self, w, out):
         backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
+
+    def blockmax(self, z, block):
+        """Block maxima of ``z`` (contiguous rows), NaN -> FLT_MAX wall."""
+        out = self.torch.empty((-(-z.shape[0] // block), -(-z.shape[1] // block)),
+                               dtype=z.dtype, device=z.device)
+        backend.blockmax_dev(self._wrap(z, np.float32), block,
+                             out=self._wrap(out, np.float32))
+        return out
 
 
 def _exchange(dist, torch, w, top, bottom, rank):
@@ -106,8 +150,55 @@ def _exchange(dist, torch, w, top, bottom, rank):
     return bool(f[0]), bool(f[1])
 
 
+def _all_gather(dist, torch, t, world, group):
+    """all_gather of equally shaped tensors; device tensors are staged through the
+    host under gloo (the CPU rehearsal path)."""
+    stage = t.is_cuda and dist.get_backend() == "gloo"
+    src = t.cpu() if stage else t
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return [p.to(t.device) for p in parts] if stage else parts
+
+
+def coarse_ghost_guess(z_local, rank, world, solver, block=COARSE_BLOCK, group=None):
+    """Upper bounds of the filled surface on this rank's ghost rows, from a fill of
+    the whole raster coarsened to block maxima (see the module docstring).
+    Returns (top, bottom) 1-D tensors (None where there is no ghost row)."""
+    import torch
+    import torch.distributed as dist
+
+    top, bottom = rank > 0, rank < world - 1
+    owned = z_local[owned_slice(rank, world)]
+    width = z_local.shape[1]
+    mine = solver.blockmax(owned.contiguous(), block)
+    # ranks own floor or ceil(H/world) rows: pad to a common shape for the all_gather
+    counts = torch.tensor([mine.shape[0]], dtype=torch.int64)
+    all_counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    if dist.get_backend() == "gloo":
+        dist.all_gather(all_counts, counts, group=group)
+    else:
+        dev_counts = _all_gather(dist, torch, counts.to(z_local.device), world, group)
+        all_counts = [c.cpu() for c in dev_counts]
+    rows = [int(c.item()) for c in all_counts]
+    padded = torch.full((max(rows), mine.shape[1]), float("inf"), dtype=mine.dtype,
+                        device=mine.device)
+    padded[:mine.shape[0]] = mine
+    parts = _all_gather(dist, torch, padded, world, group)
+    coarse = torch.cat([p[:n] for p, n in zip(parts, rows)]).contiguous()
+    filled = torch.empty_like(coarse)
+    solver.fill(coarse, filled, 0.0, backend.FILL_INIT)
+    first = sum(rows[:rank])                       # my first coarse row in the stack
+
+    def expand(coarse_row):
+        return coarse_row.repeat_interleave(block)[:width].contiguous()
+
+    g_top = expand(filled[first - 1]) if top else None
+    g_bot = expand(filled[first + rows[rank]]) if bottom else None
+    return g_top, g_bot
+
+
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
-                         max_exchanges=100000, group=None):
+                         max_exchanges=100000, group=None, coarse_block=COARSE_BLOCK):
     """Sink fill of a row-block partitioned raster.
 
     ``z_local``: torch tensor, local rows incl. ghost rows (see
@@ -124,21 +215,31 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     if bottom:
         flags |= backend.FILL_GHOST_BOTTOM
     flag_dev = None
-    visits, _ = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY)
+    sliced = world > 1
+    if world > 1 and eps == 0.0 and coarse_block:
+        g_top, g_bot = coarse_ghost_guess(z_local, rank, world, solver, coarse_block, group)
+        if top:
+            w[0].copy_(g_top)
+        if bottom:
+            w[-1].copy_(g_bot)
+        flags |= backend.FILL_GHOST_GIVEN
+    visits, _, pending = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY, sliced)
     exchanges = verifications = 0
     while world > 1:
         ch_top, ch_bot = _exchange(dist, torch, w, top, bottom, rank)
         if flag_dev is None:
             flag_dev = "cpu" if dist.get_backend() == "gloo" else w.device
-        any_changed = torch.tensor([int(ch_top or ch_bot)], dtype=torch.int32, device=flag_dev)
-        dist.all_reduce(any_changed, op=dist.ReduceOp.MAX, group=group)
+        busy = torch.tensor([int(ch_top or ch_bot or pending > 0)], dtype=torch.int32,
+                            device=flag_dev)
+        dist.all_reduce(busy, op=dist.ReduceOp.MAX, group=group)
         exchanges += 1
         if exchanges >= max_exchanges:
             raise RuntimeError("distributed sink fill did not converge")
-        if int(any_changed.item()) == 0:
+        if int(busy.item()) == 0:
             # every rank is at rest: certify the whole block (round driver, all tiles
             # due); resume only if some rank still found something to lower
-            v, lowered = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+            v, lowered, pending = solver.fill(z_local, w, eps,
+                                              backend.FILL_WARM | backend.FILL_SYNC_ONLY)
             visits += v
             verifications += 1
             again = torch.tensor([int(lowered)], dtype=torch.int32, device=flag_dev)
@@ -146,16 +247,18 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             if int(again.item()) == 0:
                 break
             continue
-        if ch_top or ch_bot:
-            act = backend.FILL_WARM | backend.FILL_NO_VERIFY
+        if ch_top or ch_bot or pending > 0:
+            # next slice: the tiles left queued plus those next to a replaced ghost row
+            act = backend.FILL_WARM | backend.FILL_RESUME | backend.FILL_NO_VERIFY
             act |= backend.FILL_ACT_TOP if ch_top else 0
             act |= backend.FILL_ACT_BOTTOM if ch_bot else 0
-            v, _ = solver.fill(z_local, w, eps, act)
+            v, _, pending = solver.fill(z_local, w, eps, act, sliced)
             visits += v
     if world == 1:
-        v, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+        v, _, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
         visits += v
-    return w, {"tile_visits": int(visits), "exchanges": exchanges}
+    return w, {"tile_visits": int(visits), "exchanges": exchanges,
+               "verifications": verifications}
 
 
 def d8_distributed(w_local, solver, out=None):

@@ -71,7 +71,8 @@ typedef enum hdem_kernel_id {
     HDEM_K_CONVOLVE = 5,
     HDEM_K_FILL_SCAN = 6,     /* (reserved)                                 */
     HDEM_K_FILL_ROUND = 7,    /* round-synchronous certifying / finishing pass */
-    HDEM_K_COUNT = 8
+    HDEM_K_BLOCKMAX = 8,      /* block-maximum coarsening (multi-GPU start values) */
+    HDEM_K_COUNT = 9
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -105,6 +106,7 @@ typedef struct hdem_fill_stats {
     int64_t visits_unchanged; /* visits that found nothing to lower          */
     int64_t visits_requeued;  /* visits that hit the iteration cap           */
     int64_t round_visits;     /* of tile_visits: made by the round driver    */
+    int64_t pending;          /* tiles still queued when a time slice ended  */
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */
@@ -119,8 +121,16 @@ typedef struct hdem_fill_stats {
 #define HDEM_FILL_NO_VERIFY   0x80 /* skip the certifying round pass behind the asynchronous
                                       phase: for intermediate solves of a halo-exchange loop
                                       whose last solve is a verifying one                  */
+#define HDEM_FILL_RESUME      0x100 /* WARM: keep the worklist the previous call on this context
+                                      left (a time slice that ended with tiles queued);
+                                      ACT_TOP / ACT_BOTTOM add the tile rows next to a replaced
+                                      ghost row.  Implies NO_VERIFY.                      */
 #define HDEM_FILL_GHOST_TOP   0x10 /* INIT: row 0 / row H-1 is a ghost row owned by the   */
 #define HDEM_FILL_GHOST_BOTTOM 0x20 /* neighbouring row block: starts at +inf, not at Z    */
+#define HDEM_FILL_GHOST_GIVEN 0x200 /* INIT with GHOST_TOP / GHOST_BOTTOM: the ghost rows of w
+                                      already hold upper bounds of the filled surface (the
+                                      caller's guess, e.g. from a coarse solve): start from
+                                      those instead of +inf.  Must be >= the true fill.    */
 
 /* eps = 0 gives flats (exact, order-independent, bit-reproducible);
  * eps > 0 is the Planchon-Darboux gradient.  max_rounds <= 0 -> default. */
@@ -129,6 +139,19 @@ int hdem_sinkfill_f32(hdem_ctx *ctx, const float *z, int H, int W, float eps,
 int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W,
                           float eps, int max_rounds, int flags, float *w,
                           hdem_fill_stats *stats);
+/* Time slice of the asynchronous phase in microseconds (0 = run to convergence, the
+ * default).  With a slice, an INIT/WARM call that has HDEM_FILL_NO_VERIFY returns
+ * HDEM_OK with stats->pending > 0 when the slice ended first; continue with
+ * HDEM_FILL_WARM | HDEM_FILL_RESUME.  This is what lets row blocks on different
+ * GPUs trade ghost rows every millisecond instead of once per local convergence. */
+int hdem_set_fill_slice_us(hdem_ctx *ctx, int microseconds);
+
+/* Block maximum: out[i][j] = max of z over rows [i*b, (i+1)*b) x columns [j*b, (j+1)*b)
+ * (clipped to the raster; a block with a NaN cell gives FLT_MAX), b a power of two in
+ * 4..256, out is ceil(H/b) x ceil(W/b).  The sink fill of this coarse raster bounds the
+ * sink fill of z from above cell by cell -- the multi-GPU path uses it as the start value
+ * of the ghost rows (new work; the reference is single process). */
+int hdem_blockmax_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, int b, float *out);
 
 /* ---- A5  Convolve.apply + Around.apply -----------------------------------
  * extension_filters.py:166-184 (scipy.ndimage.convolve, mode='reflect',

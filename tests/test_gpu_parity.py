@@ -363,7 +363,7 @@ def test_virtual_rank_partition_on_hip(world, H, W):
     for b in blocks:
         flags = backend.FILL_INIT | (backend.FILL_GHOST_TOP if b["top"] else 0) \
             | (backend.FILL_GHOST_BOTTOM if b["bot"] else 0)
-        solver.fill(b["z"], b["w"], 0.0, flags)
+        solver.fill(b["z"], b["w"], 0.0, flags)      # (unsliced: runs to its fixed point)
     for _ in range(1000):
         torch.cuda.synchronize()
         sends = [(b["w"][1].clone(), b["w"][-2].clone()) for b in blocks]
@@ -398,6 +398,133 @@ def test_virtual_rank_partition_on_hip(world, H, W):
         codes.append(d[P.owned_slice(r, world)].cpu().numpy())
     assert np.array_equal(np.concatenate(codes), c_oracle.d8(want))
     solver.ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("shape,block", [((5, 7), 4), ((64, 256), 16), ((130, 1031), 32),
+                                         ((257, 515), 8), ((300, 70), 64), ((1000, 2049), 256)])
+def test_blockmax_matches_numpy(shape, block):
+    z = oracle.synth_dem(*shape)
+    if shape[0] > 100:
+        z[shape[0] // 2, shape[1] // 3] = np.nan
+    got = backend.blockmax_dev(backend.DeviceRaster.from_host(z), block).to_host()
+    zn = np.where(np.isnan(z), np.finfo(np.float32).max, z)
+    ch, cw = -(-shape[0] // block), -(-shape[1] // block)
+    pad = np.full((ch * block, cw * block), -np.inf, dtype=np.float32)
+    pad[:shape[0], :shape[1]] = zn
+    assert np.array_equal(got, pad.reshape(ch, block, cw, block).max(axis=(1, 3)))
+    with pytest.raises(ValueError):
+        backend.blockmax_dev(backend.DeviceRaster.from_host(z), 24)
+
+
+def test_given_ghost_rows_are_start_values_not_pins():
+    """INIT | GHOST_* | GHOST_GIVEN: the block relaxes against the caller's ghost rows
+    (kept as given, raised to the terrain where below it, NaN where the terrain is
+    nodata), and the result equals the fill of the raster whose ring rows hold them."""
+    z = oracle.synth_dem(400, 520)
+    z[0, 50:60] = np.nan
+    guess_top = np.full(520, 110.0, dtype=np.float32)
+    guess_top[200:260] = -50.0                      # below the terrain: raised to it
+    guess_bot = np.full(520, 104.0, dtype=np.float32)
+    zd = backend.DeviceRaster.from_host(z)
+    w0 = np.zeros_like(z)
+    w0[0], w0[-1] = guess_top, guess_bot
+    wd = backend.DeviceRaster.from_host(w0)
+    backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_INIT | backend.FILL_GHOST_TOP
+                         | backend.FILL_GHOST_BOTTOM | backend.FILL_GHOST_GIVEN)
+    got = wd.to_host()
+    zeq = z.copy()
+    zeq[0, 1:-1] = np.where(np.isnan(z[0, 1:-1]), np.nan, np.maximum(guess_top, z[0])[1:-1])
+    zeq[-1, 1:-1] = np.maximum(guess_bot, z[-1])[1:-1]
+    want = c_oracle.sinkfill_pflood(zeq)
+    assert np.array_equal(np.nan_to_num(got, nan=-1), np.nan_to_num(want, nan=-1))
+
+
+def test_time_sliced_fill_resumes_to_the_same_bits():
+    """INIT with a short time slice leaves tiles queued; RESUME continues the same
+    worklist; the result and a final certifying pass agree with the oracle."""
+    z = oracle.synth_dem(1536, 2048)
+    ctx = backend.Context(0)
+    zd = backend.DeviceRaster.from_host(z, ctx=ctx)
+    wd = backend.DeviceRaster.empty(z.shape, np.float32, ctx=ctx)
+    try:
+        ctx.set_fill_slice_us(100)
+        _, st = backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_INIT | backend.FILL_NO_VERIFY)
+        slices, visits = 1, st["tile_visits"]
+        assert st["pending"] > 0 and not st["converged"]
+        while st["pending"] > 0:
+            _, st = backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_WARM | backend.FILL_RESUME)
+            slices += 1
+            visits += st["tile_visits"]
+            assert slices < 10000
+        assert slices > 2 and st["converged"]
+        ctx.set_fill_slice_us(0)
+        # a resume with nothing queued and nothing activated is a no-op
+        _, st = backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_WARM | backend.FILL_RESUME)
+        assert st["tile_visits"] == 0 and st["converged"]
+        _, st = backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+        assert st["tile_visits"] == st["visits_unchanged"]          # already the fixed point
+        assert np.array_equal(wd.to_host(), c_oracle.sinkfill_pflood(z))
+        # resume after the round driver ran: no worklist, but quiescent -> still a no-op-ish
+        # call that must not corrupt anything
+        _, st = backend.sinkfill_dev(zd, out=wd, flags=backend.FILL_WARM | backend.FILL_RESUME
+                                     | backend.FILL_ACT_TOP)
+        assert st["converged"] and st["tile_visits"] == st["visits_unchanged"]
+        assert np.array_equal(wd.to_host(), c_oracle.sinkfill_pflood(z))
+    finally:
+        zd.free()
+        wd.free()
+        ctx.close()
+
+
+@pytest.mark.parametrize("world,H,W,slice_us", [(2, 700, 900, 50), (4, 2048, 1024, 100)])
+def test_virtual_rank_partition_time_sliced(world, H, W, slice_us):
+    """The schedule of partition.sinkfill_distributed (slice, exchange, resume) on
+    virtual ranks: one context per block, as one process per GPU would have."""
+    torch = pytest.importorskip("torch")
+    from hydrodem_amd import partition as P
+    z = oracle.synth_dem(H, W)
+    blocks = []
+    for r in range(world):
+        g0, g1, top, bot = P.local_range(r, world, H)
+        zt = torch.from_numpy(z[g0:g1].copy()).cuda()
+        blocks.append({"z": zt, "w": torch.empty_like(zt), "top": top, "bot": bot,
+                       "solver": P.HipLocalSolver(0, slice_us=slice_us, own_context=True)})
+    sliced_out = 0
+    for b in blocks:
+        flags = backend.FILL_INIT | backend.FILL_NO_VERIFY \
+            | (backend.FILL_GHOST_TOP if b["top"] else 0) \
+            | (backend.FILL_GHOST_BOTTOM if b["bot"] else 0)
+        b["pending"] = b["solver"].fill(b["z"], b["w"], 0.0, flags, True)[2]
+    for _ in range(100000):
+        torch.cuda.synchronize()
+        sends = [(b["w"][1].clone(), b["w"][-2].clone()) for b in blocks]
+        busy = False
+        for r, b in enumerate(blocks):
+            flags = backend.FILL_WARM | backend.FILL_RESUME | backend.FILL_NO_VERIFY
+            if b["top"] and not torch.equal(sends[r - 1][1], b["w"][0]):
+                b["w"][0].copy_(sends[r - 1][1])
+                flags |= backend.FILL_ACT_TOP
+            if b["bot"] and not torch.equal(sends[r + 1][0], b["w"][-1]):
+                b["w"][-1].copy_(sends[r + 1][0])
+                flags |= backend.FILL_ACT_BOTTOM
+            if flags & (backend.FILL_ACT_TOP | backend.FILL_ACT_BOTTOM) or b["pending"] > 0:
+                busy = True
+                sliced_out += b["pending"] > 0
+                torch.cuda.synchronize()
+                b["pending"] = b["solver"].fill(b["z"], b["w"], 0.0, flags, True)[2]
+        if not busy:
+            lowered = [b["solver"].fill(b["z"], b["w"], 0.0,
+                                        backend.FILL_WARM | backend.FILL_SYNC_ONLY)[1]
+                       for b in blocks]
+            assert not any(lowered)
+            break
+    assert sliced_out > 0                    # the slices did cut solves short
+    torch.cuda.synchronize()
+    got = np.concatenate([b["w"][P.owned_slice(r, world)].cpu().numpy()
+                          for r, b in enumerate(blocks)])
+    assert np.array_equal(got, c_oracle.sinkfill_pflood(z))
+    for b in blocks:
+        b["solver"].ctx.close()
 
 
 # --------------------------------------------------------------------------

@@ -171,14 +171,17 @@ def test_python_constants_match_the_header():
     assert defines["HDEM_FILL_GHOST_BOTTOM"] == backend.FILL_GHOST_BOTTOM
     assert defines["HDEM_FILL_SYNC_ONLY"] == backend.FILL_SYNC_ONLY
     assert defines["HDEM_FILL_NO_VERIFY"] == backend.FILL_NO_VERIFY
+    assert defines["HDEM_FILL_RESUME"] == backend.FILL_RESUME
+    assert defines["HDEM_FILL_GHOST_GIVEN"] == backend.FILL_GHOST_GIVEN
     enums = dict(re.findall(r"\b(HDEM_(?:K|ERR)_[A-Z0-9_]+|HDEM_OK)\s*=\s*(\d+)", header))
     assert int(enums["HDEM_K_FILL_TILE"]) == backend.K_FILL_TILE
     assert int(enums["HDEM_K_FILL_ROUND"]) == backend.K_FILL_ROUND
+    assert int(enums["HDEM_K_BLOCKMAX"]) == backend.K_BLOCKMAX
     assert int(enums["HDEM_K_GROVES"]) == backend.K_GROVES
     assert int(enums["HDEM_ERR_WINDOW_EVEN"]) == backend.WINDOW_EVEN
     assert int(enums["HDEM_ERR_WINDOW_HIGH"]) == backend.WINDOW_HIGH
     assert int(enums["HDEM_ERR_NOT_CONVERGED"]) == backend.NOT_CONVERGED
     # struct layouts the binding mirrors
     # struct layouts the binding mirrors: 6 int32 + 6 int64 / 2 int64 + 1 double
-    assert ctypes.sizeof(backend.FillStats) == 72 and backend.FillStats.round_visits.offset == 64
+    assert ctypes.sizeof(backend.FillStats) == 80 and backend.FillStats.pending.offset == 72
     assert ctypes.sizeof(backend.KernelStat) == 24

@@ -21,16 +21,23 @@ from hydrodem_amd import backend, partition as P
 
 
 class NumpyLocalSolver:
-    """Oracle-backed stand-in for HipLocalSolver (same two methods)."""
+    """Oracle-backed stand-in for HipLocalSolver (same two methods).  A "time slice"
+    is ``slice_sweeps`` Jacobi sweeps; an unfinished slice reports one pending tile."""
 
-    def fill(self, z, w, eps, flags):
+    def __init__(self, slice_sweeps=3):
+        self.slice_sweeps = slice_sweeps
+
+    def fill(self, z, w, eps, flags, sliced=False):
         zn, wn = z.numpy(), w.numpy()
         if not flags & backend.FILL_WARM:
             w0 = oracle.sinkfill_init(zn)
+            given = bool(flags & backend.FILL_GHOST_GIVEN)
             if flags & backend.FILL_GHOST_TOP:
-                w0[0, 1:-1] = np.where(np.isnan(zn[0, 1:-1]), zn[0, 1:-1], np.inf)
+                start = np.maximum(wn[0, 1:-1], zn[0, 1:-1]) if given else np.inf
+                w0[0, 1:-1] = np.where(np.isnan(zn[0, 1:-1]), zn[0, 1:-1], start)
             if flags & backend.FILL_GHOST_BOTTOM:
-                w0[-1, 1:-1] = np.where(np.isnan(zn[-1, 1:-1]), zn[-1, 1:-1], np.inf)
+                start = np.maximum(wn[-1, 1:-1], zn[-1, 1:-1]) if given else np.inf
+                w0[-1, 1:-1] = np.where(np.isnan(zn[-1, 1:-1]), zn[-1, 1:-1], start)
             wn[:] = w0
         sweeps = 0
         while True:
@@ -38,10 +45,20 @@ class NumpyLocalSolver:
             wn[:] = new
             sweeps += 1
             if changed == 0:
-                return sweeps, sweeps > 1
+                return sweeps, sweeps > 1, 0
+            if sliced and flags & backend.FILL_NO_VERIFY and sweeps >= self.slice_sweeps:
+                return sweeps, True, 1
 
     def d8(self, w, out):
         out.numpy()[:] = oracle.d8_flow_direction(w.numpy())
+
+    def blockmax(self, z, block):
+        import torch
+        zn = np.where(np.isnan(z.numpy()), np.finfo(np.float32).max, z.numpy())
+        ch, cw = -(-zn.shape[0] // block), -(-zn.shape[1] // block)
+        pad = np.full((ch * block, cw * block), -np.inf, dtype=np.float32)
+        pad[:zn.shape[0], :zn.shape[1]] = zn
+        return torch.from_numpy(pad.reshape(ch, block, cw, block).max(axis=(1, 3)))
 
 
 def _free_port():
@@ -50,7 +67,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, H, W, eps, variant, nodata, outdir):
+def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,7 +80,8 @@ def _worker(rank, world, port, H, W, eps, variant, nodata, outdir):
             z = full[g0:g1].copy()
         zt = torch.from_numpy(z)
         solver = NumpyLocalSolver()
-        w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps)
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps,
+                                         coarse_block=coarse_block)
         d = P.d8_distributed(w, solver)
         own = P.owned_slice(rank, world)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), w=w.numpy()[own], d=d.numpy()[own],
@@ -72,17 +90,41 @@ def _worker(rank, world, port, H, W, eps, variant, nodata, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,H,W,eps,variant,nodata", [
-    (2, 96, 80, 0.0, "rough", False),
-    (2, 101, 64, 0.0, "srtm", False),
-    (3, 90, 70, 0.0, "rough", False),
-    (2, 64, 48, 1e-3, "rough", False),
-    (2, 80, 60, 0.0, "rough", True),
+@pytest.mark.parametrize("block", [4, 8, 32])
+@pytest.mark.parametrize("nodata", [False, True])
+def test_coarse_fill_bounds_the_fine_fill_from_above(block, nodata):
+    """The property the ghost-row start values rest on: the fill of the block-maximum
+    raster, expanded back, is >= the fill of the raster, cell by cell (walls where a
+    block holds nodata)."""
+    z = oracle.synth_dem(150, 203)
+    if nodata:
+        z[40:44, 100:180] = np.nan
+        z[120, 7] = np.nan
+    fine = c_oracle.sinkfill_pflood(z)
+    coarse = NumpyLocalSolver().blockmax(torch.from_numpy(z), block).numpy()
+    assert coarse.shape == (-(-150 // block), -(-203 // block))
+    bound = c_oracle.sinkfill_pflood(coarse)
+    up = np.repeat(np.repeat(bound, block, axis=0), block, axis=1)[:150, :203]
+    ok = ~np.isnan(fine)
+    assert np.all(up[ok] >= fine[ok])
+    assert np.isfinite(up).all()
+
+
+@pytest.mark.parametrize("world,H,W,eps,variant,nodata,coarse_block", [
+    (2, 96, 80, 0.0, "rough", False, 4),
+    (2, 101, 64, 0.0, "srtm", False, 4),
+    (3, 90, 70, 0.0, "rough", False, 4),
+    (2, 64, 48, 1e-3, "rough", False, 4),         # gradient: no coarse solve either
+    (2, 80, 60, 0.0, "rough", True, 4),
+    (3, 100, 90, 0.0, "rough", True, 4),
+    (2, 96, 80, 0.0, "rough", False, 0),          # ghost rows start at +inf (no coarse solve)
+    (3, 75, 70, 0.0, "srtm", False, 8),
 ])
-def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata):
+def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata,
+                                                     coarse_block):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, H, W, eps, variant, nodata, str(tmp_path)),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, H, W, eps, variant, nodata, str(tmp_path),
+                            coarse_block), nprocs=world, join=True)
     z = oracle.synth_dem(H, W, variant=variant)
     if nodata:
         z[H // 2 - 3:H // 2 + 3, 10:20] = np.nan

@@ -1,0 +1,55 @@
+"""What would a good initial guess of the ghost rows buy the row-block sink fill?
+Solve an N-rank problem to the end (virtual ranks), then re-solve each block from
+scratch with its ghost rows pinned at (final value + delta).  Exploration only.
+usage: python tools/ghost_guess.py N [rows_per_rank] [cols]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hydrodem_amd import backend as B, partition as P
+import oracle
+
+N = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
+H = N * S
+blocks = []
+for r in range(N):
+    g0, g1, top, bot = P.local_range(r, N, H)
+    zt = torch.from_numpy(oracle.synth_dem(H, W, row0=g0, rows=g1 - g0)).cuda()
+    blocks.append({"z": zt, "w": torch.empty_like(zt), "top": top, "bot": bot,
+                   "solver": P.HipLocalSolver(0, own_context=True)})
+def fill(b, flags, z=None, w=None):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    v, lowered, _ = b["solver"].fill(b["z"] if z is None else z, b["w"] if w is None else w, 0.0, flags)
+    torch.cuda.synchronize(); return time.perf_counter() - t, v, lowered
+for b in blocks:
+    fill(b, B.FILL_INIT | B.FILL_NO_VERIFY | (B.FILL_GHOST_TOP if b["top"] else 0) | (B.FILL_GHOST_BOTTOM if b["bot"] else 0))
+while True:
+    sends = [(b["w"][1].clone(), b["w"][-2].clone()) for b in blocks]
+    n = 0
+    for r, b in enumerate(blocks):
+        flags = B.FILL_WARM | B.FILL_NO_VERIFY
+        if b["top"] and not torch.equal(sends[r - 1][1], b["w"][0]):
+            b["w"][0].copy_(sends[r - 1][1]); flags |= B.FILL_ACT_TOP
+        if b["bot"] and not torch.equal(sends[r + 1][0], b["w"][-1]):
+            b["w"][-1].copy_(sends[r + 1][0]); flags |= B.FILL_ACT_BOTTOM
+        if flags & (B.FILL_ACT_TOP | B.FILL_ACT_BOTTOM):
+            fill(b, flags); n += 1
+    if n == 0:
+        break
+print("solved; per-block re-solve with ghost rows pinned at final + delta:")
+for r, b in enumerate(blocks):
+    ntile = ((b["z"].shape[0] - 2 + 61) // 62) * ((W - 2 + 61) // 62)
+    for delta in (0.0, 0.5, 2.0, 4.0, 8.0):
+        zm = b["z"].clone(); w2 = torch.empty_like(zm)
+        if b["top"]: zm[0] = torch.maximum(b["w"][0] + delta, zm[0])
+        if b["bot"]: zm[-1] = torch.maximum(b["w"][-1] + delta, zm[-1])
+        t, v, _ = fill(b, B.FILL_INIT | B.FILL_NO_VERIFY, zm, w2)
+        # then the correction when the true rows arrive
+        t2 = v2 = 0
+        if delta > 0:
+            if b["top"]: zm[0] = b["w"][0]; w2[0] = b["w"][0]
+            if b["bot"]: zm[-1] = b["w"][-1]; w2[-1] = b["w"][-1]
+            t2, v2, _ = fill(b, B.FILL_WARM | B.FILL_NO_VERIFY | (B.FILL_ACT_TOP if b["top"] else 0) | (B.FILL_ACT_BOTTOM if b["bot"] else 0), zm, w2)
+        same = torch.equal(w2[1:-1], b["w"][1:-1])
+        print(f"  rank {r} delta {delta:4.1f} m: solve {t*1e3:7.2f} ms ({v/ntile:5.1f} visits/tile)  correction {t2*1e3:6.2f} ms ({v2/ntile:4.1f}/tile)  exact={same}")
