@@ -106,6 +106,19 @@ class HipLocalSolver:
     def d8(self, w, out):
         backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
 
+    def groves(self, img, mask, window_size, threshold, iterations):
+        out = self.torch.empty_like(img)
+        backend.groves_dev(self._wrap(img, np.float32), self._wrap(mask, np.uint8),
+                           window_size, threshold, iterations,
+                           out=self._wrap(out, np.float32))
+        return out
+
+    def boxmean(self, x, do_round):
+        dt = np.float64 if x.dtype == self.torch.float64 else np.float32
+        out = self.torch.empty_like(x)
+        backend.boxmean3_dev(self._wrap(x, dt), do_round, out=self._wrap(out, dt))
+        return out
+
     def blockmax(self, z, block):
         """Block maxima of ``z`` (contiguous rows), NaN -> FLT_MAX wall."""
         out = self.torch.empty((-(-z.shape[0] // block), -(-z.shape[1] // block)),
@@ -271,6 +284,59 @@ def d8_distributed(w_local, solver, out=None):
         if out is None else out
     solver.d8(w_local, out)
     return out
+
+
+def halo_exchange(owned, halo, rank, world, group=None):
+    """Owned rows plus ``halo`` rows of each neighbour (one batched isend/irecv
+    group; SURVEY 8e: D8 / box mean 1 row, quadratic 7 rows per pass).  Returns
+    (extended tensor, rows on top that belong to rank-1, rows at the bottom that
+    belong to rank+1).  Ranks must own at least ``halo`` rows."""
+    import torch
+    import torch.distributed as dist
+
+    top, bottom = rank > 0, rank < world - 1
+    if owned.shape[0] < halo:
+        raise ValueError(f"rank {rank} owns {owned.shape[0]} rows, fewer than the halo of {halo}")
+    stage = owned.is_cuda and dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if stage else owned.device
+    ops, r_top, r_bot = [], None, None
+    if top:
+        r_top = torch.empty((halo,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=dev)
+        ops.append(dist.P2POp(dist.isend, owned[:halo].to(dev).contiguous(), rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, r_top, rank - 1, group))
+    if bottom:
+        r_bot = torch.empty((halo,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=dev)
+        ops.append(dist.P2POp(dist.isend, owned[-halo:].to(dev).contiguous(), rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, r_bot, rank + 1, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    parts = ([r_top.to(owned.device)] if top else []) + [owned] + \
+            ([r_bot.to(owned.device)] if bottom else [])
+    return torch.cat(parts).contiguous(), halo if top else 0, halo if bottom else 0
+
+
+def groves_distributed(img_owned, groves_owned, rank, world, solver, iterations=3,
+                       window_size=15, threshold=1.5, group=None):
+    """``GrovesCorrectionsIter`` on a row-block partitioned raster: one exchange of
+    ``iterations * (window_size // 2)`` rows each way, then the fused passes run on the
+    extended block and the overlap is recomputed instead of exchanged again.  Pass k
+    is right from row k * (window_size // 2) of the extended block on, so after the
+    last pass the owned rows are; the raster's own first and last rows keep the
+    reference's untouched border ring because they are the block's."""
+    halo = iterations * (window_size // 2)
+    img, t, b = halo_exchange(img_owned, halo, rank, world, group)
+    mask, _, _ = halo_exchange(groves_owned, halo, rank, world, group)
+    out = solver.groves(img, mask, window_size, threshold, iterations)
+    return out[t:out.shape[0] - b]
+
+
+def boxmean_distributed(x_owned, rank, world, solver, do_round=True, group=None):
+    """``PostProcessingFinal`` (3 x 3 mean, reflect at the raster border, optional
+    rounding) on a row-block partitioned raster: one ghost row each way."""
+    x, t, b = halo_exchange(x_owned, 1, rank, world, group)
+    out = solver.boxmean(x, do_round)
+    return out[t:out.shape[0] - b]
 
 
 def owned_slice(rank, world):

@@ -40,8 +40,16 @@ def _worker(rank, world, port, H, W, outdir):
         d = P.d8_distributed(w, solver)
         torch.cuda.synchronize()
         own = P.owned_slice(rank, world)
+        # the one-exchange stencils: groves x3 (21-row halo), box mean (1 row)
+        r0, r1 = P.row_range(rank, world, H)
+        img = torch.from_numpy(oracle.synth_dem(H, W, pits=False)[r0:r1].copy()).cuda()
+        mask = torch.from_numpy(oracle.synth_groves(H, W)[r0:r1].copy()).cuda()
+        gr = P.groves_distributed(img, mask, rank, world, solver)
+        bm = P.boxmean_distributed(gr, rank, world, solver)
+        torch.cuda.synchronize()
         np.savez(os.path.join(outdir, f"r{rank}.npz"), w=w.cpu().numpy()[own],
-                 d=d.cpu().numpy()[own], exchanges=info["exchanges"])
+                 d=d.cpu().numpy()[own], exchanges=info["exchanges"],
+                 groves=gr.cpu().numpy(), boxmean=bm.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -56,3 +64,14 @@ def test_two_rank_rehearsal_on_one_gpu(tmp_path, built, world, H, W):
     assert np.array_equal(np.concatenate([p["w"] for p in parts]), want_w)
     assert np.array_equal(np.concatenate([p["d"] for p in parts]), c_oracle.d8(want_w))
     assert all(int(p["exchanges"]) >= 2 for p in parts)
+    # groves: the kernel sums float32 offsets from a per-strip reference level, so a
+    # different block origin may round the last bit differently: <= 1e-4 m (the bar of
+    # SURVEY 8d), not bit-equal.  Box mean + round of the same input: bit for bit.
+    from hydrodem_amd import backend
+    img, mask = oracle.synth_dem(H, W, pits=False), oracle.synth_groves(H, W)
+    whole = backend.groves_dev(backend.DeviceRaster.from_host(img),
+                               backend.DeviceRaster.from_host(mask)).to_host()
+    got_g = np.concatenate([p["groves"] for p in parts])
+    assert got_g.shape == whole.shape and np.abs(got_g - whole).max() <= 1e-4
+    assert np.array_equal(np.concatenate([p["boxmean"] for p in parts]),
+                          backend.boxmean3_dev(backend.DeviceRaster.from_host(got_g)).to_host())

@@ -52,8 +52,15 @@ class NumpyLocalSolver:
     def d8(self, w, out):
         out.numpy()[:] = oracle.d8_flow_direction(w.numpy())
 
+    def groves(self, img, mask, window_size, threshold, iterations):
+        return torch.from_numpy(oracle.groves_exact64(
+            img.numpy(), mask.numpy(), iterations, window_size, threshold)[0].astype(np.float32))
+
+    def boxmean(self, x, do_round):
+        f = oracle.boxmean3_round if do_round else oracle.boxmean3
+        return torch.from_numpy(f(x.numpy()))
+
     def blockmax(self, z, block):
-        import torch
         zn = np.where(np.isnan(z.numpy()), np.finfo(np.float32).max, z.numpy())
         ch, cw = -(-zn.shape[0] // block), -(-zn.shape[1] // block)
         pad = np.full((ch * block, cw * block), -np.inf, dtype=np.float32)
@@ -137,6 +144,43 @@ def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps,
     assert np.array_equal(np.nan_to_num(got_w, nan=-1), np.nan_to_num(want_w, nan=-1))
     assert np.array_equal(got_d, want_d)
     assert all(int(p["exchanges"]) >= 2 for p in parts)     # information did cross the seam
+
+
+def _stencil_worker(rank, world, port, H, W, iters, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r0, r1 = P.row_range(rank, world, H)
+        img = torch.from_numpy(oracle.synth_dem(H, W, pits=False)[r0:r1].copy())
+        mask = torch.from_numpy(oracle.synth_groves(H, W)[r0:r1].copy())
+        solver = NumpyLocalSolver()
+        gr = P.groves_distributed(img, mask, rank, world, solver, iterations=iters)
+        bm = P.boxmean_distributed(gr, rank, world, solver)
+        np.savez(os.path.join(outdir, f"s{rank}.npz"), groves=gr.numpy(), boxmean=bm.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,iters", [(2, 120, 64, 3), (3, 150, 50, 2)])
+def test_partitioned_groves_and_boxmean_equal_unpartitioned(tmp_path, world, H, W, iters):
+    """One halo exchange (iters * 7 rows, then 1 row), overlap recomputed: the owned
+    rows equal the unpartitioned result of the same solver."""
+    mp.spawn(_stencil_worker, args=(world, _free_port(), H, W, iters, str(tmp_path)),
+             nprocs=world, join=True)
+    solver = NumpyLocalSolver()
+    img = torch.from_numpy(oracle.synth_dem(H, W, pits=False))
+    mask = torch.from_numpy(oracle.synth_groves(H, W))
+    want_g = solver.groves(img, mask, 15, 1.5, iters)
+    want_b = solver.boxmean(want_g, True)
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    assert np.array_equal(np.concatenate([p["groves"] for p in parts]), want_g.numpy())
+    assert np.array_equal(np.concatenate([p["boxmean"] for p in parts]), want_b.numpy())
+
+
+def test_halo_exchange_rejects_blocks_thinner_than_the_halo():
+    with pytest.raises(ValueError, match="fewer than the halo"):
+        P.halo_exchange(torch.zeros(5, 8), 21, 0, 1)
 
 
 def test_row_ranges_tile_the_raster():
