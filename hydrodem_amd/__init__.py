@@ -21,8 +21,13 @@ from .filters import Filter, ComposedFilter, ComposedFilterResults  # noqa: F401
 from .filters.custom_filters import (QuadraticFilter, MaskTallGroves,  # noqa: F401
                                      GrovesCorrection, GrovesCorrectionsIter,
                                      PostProcessingFinal, SinkFill,
-                                     D8FlowDirection, HydroConditioning)
-from .filters.extension_filters import Convolve, Around  # noqa: F401
+                                     D8FlowDirection, HydroConditioning,
+                                     ExpandFilter, IsolatedPoints, BlanksFourier,
+                                     DetectBlanksFourier, MaskFourier, FourierInitial,
+                                     FourierProcessQuarters, DetectApplyFourier)
+from .filters.extension_filters import (Convolve, Around, AbsoluteValues,  # noqa: F401
+                                        FourierTransform, FourierITransform,
+                                        FourierShift, FourierIShift)
 from .filters.simple_filters import (LowerThan, GreaterThan, BooleanToInteger,  # noqa: F401
                                      ProductFilter, AdditionFilter,
                                      SubtractionFilter)

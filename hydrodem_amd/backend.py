@@ -26,7 +26,7 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 
 # kernel ids for the timing query
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
-K_BLOCKMAX = 8
+K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
@@ -75,6 +75,12 @@ SIGNATURES = {
     "hdem_sinkfill_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp,
                               _c.POINTER(FillStats)],
     "hdem_blockmax_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_fourier_destripe_f32": [_vp, _vp, _i, _i, _vp, _vp],
+    "hdem_fourier_destripe_f32_dev": [_vp, _vp, _i, _i, _vp, _vp],
+    "hdem_blanks_fourier_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_isolated_points_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_expand_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_fft2_c2c_f32_dev": [_vp, _vp, _i, _i, _i],
     "hdem_boxmean3_f32": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f64": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
@@ -231,7 +237,8 @@ def device_count():
     return n.value
 
 
-_DTYPES = {np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.uint8)}
+_DTYPES = {np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.uint8),
+           np.dtype(np.complex64)}
 
 
 class DeviceRaster:
@@ -338,6 +345,61 @@ def blockmax_dev(z, block, out=None):
     c.check(c.lib.hdem_blockmax_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], int(block),
                                         out.ptr))
     return out
+
+
+def fourier_destripe_dev(dem, out=None, mask=None):
+    """DetectApplyFourier on a device raster; ``mask`` (uint8 raster) optionally
+    receives the reference's ``masks_fourier`` (shifted coordinates)."""
+    _need(dem, np.float32)
+    c = dem.ctx
+    out = out or DeviceRaster.empty(dem.shape, np.float32, c)
+    if mask is not None:
+        _need(mask, np.uint8)
+    quarter = (dem.shape[0] // 2 - 10, dem.shape[1] // 2 - 10)
+    c.check(c.lib.hdem_fourier_destripe_f32_dev(c.handle, dem.ptr, dem.shape[0], dem.shape[1],
+                                                out.ptr, mask.ptr if mask is not None else None),
+            window=55, shape=tuple(max(q, 0) for q in quarter))
+    return out
+
+
+def blanks_fourier_dev(q, found=None):
+    """One BlanksFourier pass: returns the byte mask of cells above 4x their hollow
+    mean; ``q`` is rewritten with those cells zeroed."""
+    _need(q, np.float32)
+    c = q.ctx
+    found = found or DeviceRaster.empty(q.shape, np.uint8, c)
+    c.check(c.lib.hdem_blanks_fourier_f32_dev(c.handle, q.ptr, q.shape[0], q.shape[1],
+                                              found.ptr), window=55, shape=q.shape)
+    return found
+
+
+def isolated_points_dev(mask, window_size=3, out=None):
+    _need(mask, np.uint8)
+    c = mask.ctx
+    out = out or DeviceRaster.empty(mask.shape, np.uint8, c)
+    c.check(c.lib.hdem_isolated_points_u8_dev(c.handle, mask.ptr, mask.shape[0], mask.shape[1],
+                                              int(window_size), out.ptr),
+            window=window_size, shape=mask.shape)
+    return out
+
+
+def expand_dev(mask, window_size=13, out=None):
+    _need(mask, np.uint8)
+    c = mask.ctx
+    out = out or DeviceRaster.empty(mask.shape, np.uint8, c)
+    c.check(c.lib.hdem_expand_u8_dev(c.handle, mask.ptr, mask.shape[0], mask.shape[1],
+                                     int(window_size), out.ptr),
+            window=window_size, shape=mask.shape)
+    return out
+
+
+def fft2_dev(data, inverse=False):
+    """In-place 2-D complex64 transform; the inverse is unnormalised."""
+    _need(data, np.complex64)
+    c = data.ctx
+    c.check(c.lib.hdem_fft2_c2c_f32_dev(c.handle, data.ptr, data.shape[0], data.shape[1],
+                                        int(bool(inverse))))
+    return data
 
 
 def boxmean3_dev(x, do_round=True, out=None):
@@ -456,6 +518,43 @@ def quadratic(dem, window_size=15):
                                      dem.shape[1], int(window_size), out.ctypes.data),
             window=window_size, shape=dem.shape)
     return out
+
+
+def fourier_destripe(dem, return_mask=False):
+    c = context()
+    dem = _host2d(dem, np.float32)
+    out = np.empty_like(dem)
+    mask = np.empty(dem.shape, dtype=np.uint8) if return_mask else None
+    quarter = (dem.shape[0] // 2 - 10, dem.shape[1] // 2 - 10)
+    c.check(c.lib.hdem_fourier_destripe_f32(c.handle, dem.ctypes.data, dem.shape[0],
+                                            dem.shape[1], out.ctypes.data,
+                                            mask.ctypes.data if return_mask else None),
+            window=55, shape=tuple(max(q, 0) for q in quarter))
+    return (out, mask) if return_mask else out
+
+
+def blanks_fourier(q):
+    """(found float64 0/1, q * (1 - found)) like BlanksFourier.apply."""
+    qd = DeviceRaster.from_host(_host2d(q, np.float32))
+    found = blanks_fourier_dev(qd)
+    return found.to_host().astype(np.float64), qd.to_host()
+
+
+def isolated_points(mask, window_size=3):
+    m = DeviceRaster.from_host(_host2d(mask, np.uint8))
+    return isolated_points_dev(m, window_size).to_host()
+
+
+def expand(mask, window_size=13):
+    m = DeviceRaster.from_host(_host2d(np.asarray(mask) > 0, np.uint8))
+    return expand_dev(m, window_size).to_host()
+
+
+def fft2(x, inverse=False):
+    """fft2 / ifft2 (normalised) of a 2-D array in complex64."""
+    a = _host2d(x, np.complex64)
+    d = fft2_dev(DeviceRaster.from_host(a), inverse).to_host()
+    return d / np.float32(a.size) if inverse else d
 
 
 def groves(img, groves_class, window_size=15, threshold=1.5, iterations=1):

@@ -70,6 +70,7 @@ extern "C" int hdem_shutdown(hdem_ctx *ctx)
         (void)hipEventDestroy(t.stop);
     }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    hdem_fourier_release(ctx);
     if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

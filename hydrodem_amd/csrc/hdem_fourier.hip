@@ -1,0 +1,562 @@
+// Fourier destripe: DetectApplyFourier and its parts,
+// custom_filters.py:369-462 (BlanksFourier, DetectBlanksFourier), :320-366
+// (IsolatedPoints), :76-125 (ExpandFilter), :537-561 (MaskFourier), :834-1101
+// (FourierInitial, FourierProcessQuarters, DetectApplyFourier); FFT wrappers
+// extension_filters.py:348-480.
+//
+//   dem -> complex -> FFT (rocFFT, complex64 like scipy.fftpack on float32 input)
+//   -> |F| of the two upper quadrants in *shifted* coordinates, 10-cell margin
+//   -> 2 x { hollow 55x55 mean (inner 5x5 left out, cells past the quadrant edge left
+//            out), cells > 4 x mean are peaks and are zeroed for the next pass }
+//   -> peaks without a neighbour dropped, the rest dilated by 13x13 minus corners
+//   -> those frequencies and their point mirrors zeroed in F -> inverse FFT -> |.|/N
+//
+// fftshift / ifftshift never move data: every kernel that needs shifted coordinates
+// maps them (shifted i <-> unshifted (i - n/2) mod n).  The full-raster mask is only
+// materialised when the caller asks for it.
+//
+// Kernels are HBM-bound stencils.  The hollow mean is separable: a row pass makes the
+// 55- and 5-wide row sums (float64: spectra span ten decades), a column pass slides
+// both down each column, compares, and rewrites the quadrant in place.  Algorithmic
+// bytes per quadrant cell and pass: row pass 4 + 16, column pass 16 + 4 + 4 + 1.
+#include <dlfcn.h>
+
+#include <cmath>
+
+#include "hdem_internal.h"
+
+// ---------------------------------------------------------------------------
+// rocFFT, loaded on first use (the rest of the library does not need it)
+// ---------------------------------------------------------------------------
+namespace {
+
+typedef struct rocfft_plan_t *rocfft_plan;
+typedef struct rocfft_execution_info_t *rocfft_execution_info;
+enum { ROCFFT_COMPLEX_FORWARD = 0, ROCFFT_COMPLEX_INVERSE = 1 };
+enum { ROCFFT_INPLACE = 0 };
+enum { ROCFFT_SINGLE = 0 };
+
+struct rocfft_api {
+    void *handle = nullptr;
+    int (*setup)() = nullptr;
+    int (*plan_create)(rocfft_plan *, int, int, int, size_t, const size_t *, size_t,
+                       const void *) = nullptr;
+    int (*plan_destroy)(rocfft_plan) = nullptr;
+    int (*plan_get_work_buffer_size)(const rocfft_plan, size_t *) = nullptr;
+    int (*execute)(const rocfft_plan, void **, void **, rocfft_execution_info) = nullptr;
+    int (*info_create)(rocfft_execution_info *) = nullptr;
+    int (*info_destroy)(rocfft_execution_info) = nullptr;
+    int (*info_set_work_buffer)(rocfft_execution_info, void *, size_t) = nullptr;
+    int (*info_set_stream)(rocfft_execution_info, void *) = nullptr;
+};
+
+rocfft_api g_fft;
+
+int load_rocfft()
+{
+    if (g_fft.handle) return HDEM_OK;
+    const char *names[] = {"librocfft.so.0", "/opt/rocm/lib/librocfft.so.0", "librocfft.so"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    HDEM_REQUIRE(h, HDEM_ERR_HIP, "cannot load rocFFT: %s", dlerror());
+#define HDEM_SYM(field, name)                                                         \
+    do {                                                                              \
+        *(void **)(&g_fft.field) = dlsym(h, name);                                    \
+        HDEM_REQUIRE(g_fft.field, HDEM_ERR_HIP, "rocFFT lacks %s", name);             \
+    } while (0)
+    HDEM_SYM(setup, "rocfft_setup");
+    HDEM_SYM(plan_create, "rocfft_plan_create");
+    HDEM_SYM(plan_destroy, "rocfft_plan_destroy");
+    HDEM_SYM(plan_get_work_buffer_size, "rocfft_plan_get_work_buffer_size");
+    HDEM_SYM(execute, "rocfft_execute");
+    HDEM_SYM(info_create, "rocfft_execution_info_create");
+    HDEM_SYM(info_destroy, "rocfft_execution_info_destroy");
+    HDEM_SYM(info_set_work_buffer, "rocfft_execution_info_set_work_buffer");
+    HDEM_SYM(info_set_stream, "rocfft_execution_info_set_stream");
+#undef HDEM_SYM
+    HDEM_REQUIRE(g_fft.setup() == 0, HDEM_ERR_HIP, "rocfft_setup failed");
+    g_fft.handle = h;
+    return HDEM_OK;
+}
+
+}  // namespace
+
+// per-context state: plans and the work buffer for one raster shape
+struct hdem_fourier_state {
+    int H = 0, W = 0;
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+    // scratch of hdem_fourier_destripe_f32_dev, kept for the next raster of this shape
+    // (a 16384^2 destripe spends ~2 of 17 ms in hipMalloc / hipFree otherwise)
+    void *scratch = nullptr;
+};
+
+void hdem_fourier_release(hdem_ctx *ctx)
+{
+    hdem_fourier_state *s = ctx->fourier;
+    if (!s) return;
+    if (s->fwd) g_fft.plan_destroy(s->fwd);
+    if (s->inv) g_fft.plan_destroy(s->inv);
+    if (s->info) g_fft.info_destroy(s->info);
+    if (s->work) (void)hipFree(s->work);
+    if (s->scratch) (void)hipFree(s->scratch);
+    delete s;
+    ctx->fourier = nullptr;
+}
+
+namespace {
+
+int ensure_plans(hdem_ctx *ctx, int H, int W)
+{
+    if (int rc = load_rocfft()) return rc;
+    hdem_fourier_state *s = ctx->fourier;
+    if (s && s->H == H && s->W == W) return HDEM_OK;
+    hdem_fourier_release(ctx);
+    s = ctx->fourier = new hdem_fourier_state;
+    const size_t lengths[2] = {(size_t)W, (size_t)H};        // fastest dimension first
+    HDEM_REQUIRE(g_fft.plan_create(&s->fwd, ROCFFT_INPLACE, ROCFFT_COMPLEX_FORWARD, ROCFFT_SINGLE,
+                                   2, lengths, 1, nullptr) == 0,
+                 HDEM_ERR_HIP, "rocfft_plan_create (forward %d x %d) failed", H, W);
+    HDEM_REQUIRE(g_fft.plan_create(&s->inv, ROCFFT_INPLACE, ROCFFT_COMPLEX_INVERSE, ROCFFT_SINGLE,
+                                   2, lengths, 1, nullptr) == 0,
+                 HDEM_ERR_HIP, "rocfft_plan_create (inverse %d x %d) failed", H, W);
+    size_t a = 0, b = 0;
+    g_fft.plan_get_work_buffer_size(s->fwd, &a);
+    g_fft.plan_get_work_buffer_size(s->inv, &b);
+    s->work_bytes = a > b ? a : b;
+    if (s->work_bytes) HDEM_HIP_CHECK(hipMalloc(&s->work, s->work_bytes));
+    HDEM_REQUIRE(g_fft.info_create(&s->info) == 0, HDEM_ERR_HIP, "rocfft info_create failed");
+    if (s->work_bytes)
+        HDEM_REQUIRE(g_fft.info_set_work_buffer(s->info, s->work, s->work_bytes) == 0,
+                     HDEM_ERR_HIP, "rocfft set_work_buffer failed");
+    s->H = H;
+    s->W = W;
+    return HDEM_OK;
+}
+
+int run_fft(hdem_ctx *ctx, bool inverse, float2 *data)
+{
+    hdem_fourier_state *s = ctx->fourier;
+    HDEM_REQUIRE(g_fft.info_set_stream(s->info, ctx->stream) == 0, HDEM_ERR_HIP,
+                 "rocfft set_stream failed");
+    void *in[1] = {data};
+    hdem_scoped_timer tm(ctx, HDEM_K_FFT, (int64_t)s->H * s->W);
+    HDEM_REQUIRE(g_fft.execute(inverse ? s->inv : s->fwd, in, nullptr, s->info) == 0,
+                 HDEM_ERR_HIP, "rocfft_execute failed");
+    return HDEM_OK;
+}
+
+constexpr int NT = 256;
+
+// geometry of the reference's quadrants (FourierProcessQuarters.__init__, :906-925)
+struct quad_geom {
+    int ny, nx, mid_y, mid_x, y_odd, x_odd, qh, qw;
+    __host__ __device__ int col0(int second) const { return second ? mid_x + 10 + x_odd : 0; }
+};
+
+__host__ quad_geom make_geom(int H, int W)
+{
+    quad_geom g;
+    g.ny = H; g.nx = W;
+    g.mid_y = H / 2; g.y_odd = H % 2;
+    g.mid_x = W / 2; g.x_odd = W % 2;
+    g.qh = g.mid_y - 10;
+    g.qw = g.mid_x - 10;
+    return g;
+}
+
+// shifted index -> index in the transform as rocFFT / fftpack lay it out
+__device__ __forceinline__ int unshift(int i, int n) { const int u = i - n / 2; return u < 0 ? u + n : u; }
+
+// Mean of the raster, deterministic (fixed tree): partial[b] per block, then one block.
+// The transform runs on dem - mean and the mean is added back before the final |.|:
+// the same numbers as the reference's (only the zero frequency moves, which no quadrant
+// contains), at a tenth of the complex64 rounding error for elevations around 100 m.
+constexpr int SUM_BLOCKS = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double *s)
+{
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int k = NT / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+        __syncthreads();
+    }
+    return s[0];
+}
+
+__global__ __launch_bounds__(NT) void sum_partial_kernel(const float *__restrict__ x, size_t n,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double s[NT];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)SUM_BLOCKS * NT)
+        acc += (double)x[i];
+    const double t = block_sum(acc, s);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(NT) void sum_final_kernel(const double *__restrict__ partial, size_t n,
+                                                       double *__restrict__ mean)
+{
+    __shared__ double s[NT];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < SUM_BLOCKS; i += NT) acc += partial[i];
+    const double t = block_sum(acc, s);
+    if (threadIdx.x == 0) *mean = t / (double)n;
+}
+
+__global__ __launch_bounds__(NT) void to_complex_kernel(const float *__restrict__ x, size_t n,
+                                                        const double *__restrict__ mean,
+                                                        float2 *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    const double m = mean ? *mean : 0.0;
+    if (i < n) out[i] = make_float2((float)((double)x[i] - m), 0.0f);
+}
+
+// |F| of one upper quadrant (FourierInitial :857 + _get_firsts_quarters :953-966)
+__global__ __launch_bounds__(NT) void quadrant_abs_kernel(const float2 *__restrict__ F, quad_geom g,
+                                                          int second, float *__restrict__ q)
+{
+    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
+    if (j >= g.qw) return;
+    const float2 v = F[(size_t)unshift(i, g.ny) * g.nx + unshift(g.col0(second) + j, g.nx)];
+    q[(size_t)i * g.qw + j] = hypotf(v.x, v.y);
+}
+
+// Row pass of the hollow mean: sums over columns x-R..x+R and x-r..x+r of one row,
+// cells outside the array left out.  256 outputs per block from a 256 + 2R strip in LDS.
+template <int R, int r>
+__global__ __launch_bounds__(NT) void rowsum_kernel(const float *__restrict__ q, int h, int w,
+                                                    double *__restrict__ big,
+                                                    double *__restrict__ small)
+{
+    __shared__ float s[NT + 2 * R];
+    const int y = blockIdx.y, x0 = blockIdx.x * NT;
+    const float *row = q + (size_t)y * w;
+    for (int k = threadIdx.x; k < NT + 2 * R; k += NT) {
+        const int x = x0 - R + k;
+        s[k] = (x >= 0 && x < w) ? row[x] : 0.0f;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) a += (double)s[threadIdx.x + k];
+#pragma unroll
+    for (int k = R - r; k <= R + r; ++k) b += (double)s[threadIdx.x + k];
+    big[(size_t)y * w + x] = a;
+    small[(size_t)y * w + x] = b;
+}
+
+// Column pass + decision (BlanksFourier.apply :417-429): lane = column, each lane slides
+// the two window sums down SEG rows.  found: the mask of this pass; total: += found
+// (DetectBlanksFourier :457-461); q is rewritten as q * (1 - found).
+template <int R, int r>
+__global__ __launch_bounds__(64) void detect_kernel(const double *__restrict__ big,
+                                                    const double *__restrict__ small,
+                                                    float *q, int h, int w, float factor,
+                                                    int seg, uint8_t *found, uint8_t *total)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y0 = blockIdx.y * seg;
+    if (x >= w) return;
+    double sb = 0.0, ss = 0.0;
+    for (int y = max(y0 - R, 0); y <= min(y0 + R, h - 1); ++y) sb += big[(size_t)y * w + x];
+    for (int y = max(y0 - r, 0); y <= min(y0 + r, h - 1); ++y) ss += small[(size_t)y * w + x];
+    const int cols_b = min(x + R, w - 1) - max(x - R, 0) + 1;
+    const int cols_s = min(x + r, w - 1) - max(x - r, 0) + 1;
+    const int y1 = min(y0 + seg, h);
+    for (int y = y0; y < y1; ++y) {
+        const int rows_b = min(y + R, h - 1) - max(y - R, 0) + 1;
+        const int rows_s = min(y + r, h - 1) - max(y - r, 0) + 1;
+        const int cnt = rows_b * cols_b - rows_s * cols_s;
+        const size_t o = (size_t)y * w + x;
+        const float v = q[o];
+        // nanmean of an empty window is NaN and compares false
+        const bool hit = cnt > 0 && (double)v > (double)factor * ((sb - ss) / (double)cnt);
+        if (found) found[o] = hit ? 1 : 0;
+        if (total && hit) total[o] = (uint8_t)(total[o] + 1);
+        if (hit) q[o] = v * 0.0f;
+        if (y + R + 1 < h) sb += big[(size_t)(y + R + 1) * w + x];
+        if (y - R >= 0) sb -= big[(size_t)(y - R) * w + x];
+        if (y + r + 1 < h) ss += small[(size_t)(y + r + 1) * w + x];
+        if (y - r >= 0) ss -= small[(size_t)(y - r) * w + x];
+    }
+}
+
+// IsolatedPoints.apply (:344-366): interior cells equal to 1 survive only next to
+// another non-zero cell (Jacobi on the input); everything else is copied.
+__global__ __launch_bounds__(NT) void isolated_kernel(const uint8_t *__restrict__ m, int h, int w,
+                                                      int reach, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * NT + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint8_t v = m[(size_t)y * w + x];
+    if (v == 1 && y >= reach && y < h - reach && x >= reach && x < w - reach) {
+        bool any = false;
+        for (int dy = -reach; dy <= reach; ++dy)
+            for (int dx = -reach; dx <= reach; ++dx)
+                if ((dy || dx) && m[(size_t)(y + dy) * w + x + dx]) any = true;
+        v = any ? 1 : 0;
+    }
+    out[(size_t)y * w + x] = v;
+}
+
+// ExpandFilter.apply (:103-125) as a scatter (the masks are sparse): every non-zero cell
+// marks the centres whose window -- the square minus its four corners -- holds it; only
+// centres whose window fits in the array exist.  out must be zeroed.
+__global__ __launch_bounds__(NT) void expand_kernel(const uint8_t *__restrict__ m, int h, int w,
+                                                    int reach, uint8_t *out)
+{
+    const int x = blockIdx.x * NT + threadIdx.x, y = blockIdx.y;
+    if (x >= w || !m[(size_t)y * w + x]) return;
+    for (int dy = -reach; dy <= reach; ++dy) {
+        const int cy = y + dy;
+        if (cy < reach || cy >= h - reach) continue;
+        for (int dx = -reach; dx <= reach; ++dx) {
+            const int cx = x + dx;
+            if (cx < reach || cx >= w - reach) continue;
+            if ((dy == -reach || dy == reach) && (dx == -reach || dx == reach)) continue;
+            out[(size_t)cy * w + cx] = 1;
+        }
+    }
+}
+
+// _fill_complete_quarters ... _fill_complete_mask (:985-1050) + (1 - mask) * spectrum
+// (:1097-1098): a marked quadrant cell zeroes its frequency and the point mirror
+// (ny-1-i, nx-1-j in shifted coordinates -- the reference mirrors array positions, which
+// is the conjugate frequency only for odd sizes).
+__global__ __launch_bounds__(NT) void apply_mask_kernel(const uint8_t *__restrict__ m, quad_geom g,
+                                                        int second, float2 *F, uint8_t *full)
+{
+    const int j = blockIdx.x * NT + threadIdx.x, i = blockIdx.y;
+    if (j >= g.qw || !m[(size_t)i * g.qw + j]) return;
+    const int X = g.col0(second) + j;
+    const int mi = g.ny - 1 - i, mX = g.nx - 1 - X;
+    F[(size_t)unshift(i, g.ny) * g.nx + unshift(X, g.nx)] = make_float2(0.0f, 0.0f);
+    F[(size_t)unshift(mi, g.ny) * g.nx + unshift(mX, g.nx)] = make_float2(0.0f, 0.0f);
+    if (full) {
+        full[(size_t)i * g.nx + X] = 1;
+        full[(size_t)mi * g.nx + mX] = 1;
+    }
+}
+
+__global__ __launch_bounds__(NT) void abs_scale_kernel(const float2 *__restrict__ F, size_t n,
+                                                       double scale,
+                                                       const double *__restrict__ mean,
+                                                       float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const double re = (double)F[i].x * scale + *mean, im = (double)F[i].y * scale;
+    out[i] = (float)sqrt(re * re + im * im);
+}
+
+inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + NT - 1) / NT), (unsigned)h); }
+
+int check_window(int window, int h, int w)
+{
+    // SlidingWindow.window_size setter (sliding_window.py:150-156): same order of checks
+    if (window > h || window > w) {
+        hdem_set_error("Window size: %d cannot be higher than grid dimensions: (%d, %d)", window, h, w);
+        return HDEM_ERR_WINDOW_HIGH;
+    }
+    if (window % 2 != 1) {
+        hdem_set_error("Window size: %d cannot be an even number", window);
+        return HDEM_ERR_WINDOW_EVEN;
+    }
+    return HDEM_OK;
+}
+
+// One BlanksFourier pass on a device quadrant (rewritten in place).
+int blanks_pass(hdem_ctx *ctx, float *q, int h, int w, double *big, double *small,
+                uint8_t *found, uint8_t *total)
+{
+    hipStream_t st = ctx->stream;
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_ROWSUM, (int64_t)h * w);
+        hipLaunchKernelGGL((rowsum_kernel<27, 2>), grid2(w, h), dim3(NT), 0, st, q, h, w, big,
+                           small);
+    }
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_DETECT, (int64_t)h * w);
+        // rows one lane walks: long runs amortise the 2R-row start-up of the sliding sums,
+        // short ones fill the chip on small quadrants (aim for >= 8192 waves)
+        int seg = 256;
+        while (seg > 32 && (int64_t)((w + 63) / 64) * ((h + seg - 1) / seg) < 8192) seg /= 2;
+        hipLaunchKernelGGL((detect_kernel<27, 2>), dim3((w + 63) / 64, (h + seg - 1) / seg),
+                           dim3(64), 0, st, big, small, q, h, w, 4.0f, seg, found, total);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, uint8_t *found)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(q, found, h, w)) return rc;
+    if (int rc = check_window(55, h, w)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    hdem_dbuf big, small;
+    if (int rc = big.alloc((size_t)h * w * sizeof(double))) return rc;
+    if (int rc = small.alloc((size_t)h * w * sizeof(double))) return rc;
+    if (int rc = blanks_pass(ctx, q, h, w, (double *)big.p, (double *)small.p, found, nullptr))
+        return rc;
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // big / small die with this scope
+    return HDEM_OK;
+}
+
+extern "C" int hdem_isolated_points_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w,
+                                           int window, uint8_t *out)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(mask, out, h, w)) return rc;
+    HDEM_REQUIRE(mask != out, HDEM_ERR_BAD_ARG, "isolated points cannot run in place");
+    if (int rc = check_window(window, h, w)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_MASK, (int64_t)h * w);
+        hipLaunchKernelGGL(isolated_kernel, grid2(w, h), dim3(NT), 0, ctx->stream, mask, h, w,
+                           window / 2, out);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+extern "C" int hdem_expand_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w, int window,
+                                  uint8_t *out)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(mask, out, h, w)) return rc;
+    HDEM_REQUIRE(mask != out, HDEM_ERR_BAD_ARG, "expand cannot run in place");
+    if (int rc = check_window(window, h, w)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)h * w, ctx->stream));
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_MASK, (int64_t)h * w);
+        hipLaunchKernelGGL(expand_kernel, grid2(w, h), dim3(NT), 0, ctx->stream, mask, h, w,
+                           window / 2, out);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+extern "C" int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, int inverse)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(data, data, H, W)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = ensure_plans(ctx, H, W)) return rc;
+    return run_fft(ctx, inverse != 0, (float2 *)data);
+}
+
+extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W,
+                                             float *out, uint8_t *mask)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(dem, out, H, W)) return rc;
+    const quad_geom g = make_geom(H, W);
+    // what the reference's window constructors would raise on the quadrants
+    if (g.qh < 1 || g.qw < 1) {
+        hdem_set_error("Window size: %d cannot be higher than grid dimensions: (%d, %d)", 55,
+                       g.qh > 0 ? g.qh : 0, g.qw > 0 ? g.qw : 0);
+        return HDEM_ERR_WINDOW_HIGH;
+    }
+    if (int rc = check_window(55, g.qh, g.qw)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = ensure_plans(ctx, H, W)) return rc;
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)H * W, qn = (size_t)g.qh * g.qw;
+    // one allocation, carved up: spectrum | row sums (2 x float64) | quadrant | 4 byte masks |
+    // partial sums + mean
+    const size_t qn8 = (qn + 7) / 8 * 8;
+    const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(double) + qn8 * sizeof(float) +
+                         4 * qn8 + (SUM_BLOCKS + 1) * sizeof(double);
+    hdem_fourier_state *fs = ctx->fourier;
+    if (!fs->scratch) HDEM_HIP_CHECK(hipMalloc(&fs->scratch, bytes));
+    char *base = (char *)fs->scratch;
+    struct view { void *p; } F{base}, big{base + n * sizeof(float2)},
+        small{(char *)big.p + qn8 * sizeof(double)}, q{(char *)small.p + qn8 * sizeof(double)},
+        det{(char *)q.p + qn8 * sizeof(float)}, iso{(char *)det.p + qn8},
+        exp{(char *)iso.p + qn8}, exp2{(char *)exp.p + qn8};
+    double *partial = (double *)((char *)exp2.p + qn8), *mean = partial + SUM_BLOCKS;
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)n);
+        hipLaunchKernelGGL(sum_partial_kernel, dim3(SUM_BLOCKS), dim3(NT), 0, st, dem, n, partial);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(NT), 0, st, (const double *)partial, n,
+                           mean);
+        hipLaunchKernelGGL(to_complex_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st,
+                           dem, n, (const double *)mean, (float2 *)F.p);
+    }
+    if (int rc = run_fft(ctx, false, (float2 *)F.p)) return rc;
+    if (mask) HDEM_HIP_CHECK(hipMemsetAsync(mask, 0, n, st));
+    // both quadrants are detected on the untouched spectrum, then both are applied
+    for (int second = 0; second < 2; ++second) {
+        uint8_t *e = (uint8_t *)(second ? exp2.p : exp.p);
+        {
+            hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)qn);
+            hipLaunchKernelGGL(quadrant_abs_kernel, grid2(g.qw, g.qh), dim3(NT), 0, st,
+                               (const float2 *)F.p, g, second, (float *)q.p);
+        }
+        HDEM_HIP_CHECK(hipMemsetAsync(det.p, 0, qn, st));
+        for (int pass = 0; pass < 2; ++pass)
+            if (int rc = blanks_pass(ctx, (float *)q.p, g.qh, g.qw, (double *)big.p,
+                                     (double *)small.p, nullptr, (uint8_t *)det.p))
+                return rc;
+        HDEM_HIP_CHECK(hipMemsetAsync(e, 0, qn, st));
+        {
+            hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_MASK, (int64_t)qn * 2);
+            hipLaunchKernelGGL(isolated_kernel, grid2(g.qw, g.qh), dim3(NT), 0, st,
+                               (const uint8_t *)det.p, g.qh, g.qw, 1, (uint8_t *)iso.p);
+            hipLaunchKernelGGL(expand_kernel, grid2(g.qw, g.qh), dim3(NT), 0, st,
+                               (const uint8_t *)iso.p, g.qh, g.qw, 6, e);
+        }
+    }
+    for (int second = 0; second < 2; ++second) {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_MASK, (int64_t)qn);
+        hipLaunchKernelGGL(apply_mask_kernel, grid2(g.qw, g.qh), dim3(NT), 0, st,
+                           (const uint8_t *)(second ? exp2.p : exp.p), g, second, (float2 *)F.p,
+                           mask);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    if (int rc = run_fft(ctx, true, (float2 *)F.p)) return rc;
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)n);
+        hipLaunchKernelGGL(abs_scale_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st,
+                           (const float2 *)F.p, n, 1.0 / ((double)H * (double)W),
+                           (const double *)mean, out);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+extern "C" int hdem_fourier_destripe_f32(hdem_ctx *ctx, const float *dem, int H, int W, float *out,
+                                         uint8_t *mask)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(dem, out, H, W)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)H * W;
+    hdem_dbuf d_in, d_out, d_mask;
+    if (int rc = d_in.alloc(n * sizeof(float))) return rc;
+    if (int rc = d_out.alloc(n * sizeof(float))) return rc;
+    if (mask)
+        if (int rc = d_mask.alloc(n)) return rc;
+    if (int rc = hdem_memcpy_h2d(ctx, d_in.p, dem, n * sizeof(float))) return rc;
+    if (int rc = hdem_fourier_destripe_f32_dev(ctx, (const float *)d_in.p, H, W, (float *)d_out.p,
+                                               mask ? (uint8_t *)d_mask.p : nullptr))
+        return rc;
+    if (mask)
+        if (int rc = hdem_memcpy_d2h(ctx, mask, d_mask.p, n)) return rc;
+    return hdem_memcpy_d2h(ctx, out, d_out.p, n * sizeof(float));
+}

@@ -37,6 +37,8 @@ struct hdem_timed_launch {
     int64_t units;
 };
 
+struct hdem_fourier_state;            // hdem_fourier.hip: rocFFT plans of one raster shape
+
 struct hdem_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -54,6 +56,7 @@ struct hdem_ctx {
     const void *fill_last_z = nullptr, *fill_last_out = nullptr;
     bool fill_resumable = false;       // state words hold a consistent asynchronous worklist
     bool fill_quiescent = false;       // ... and the last call left nothing to do
+    hdem_fourier_state *fourier = nullptr;
     int32_t *host_counts = nullptr;    // pinned: convergence counters
     size_t host_counts_len = 0;
 };
@@ -68,6 +71,7 @@ struct hdem_scoped_timer {
 };
 
 int hdem_fold_profile(hdem_ctx *ctx);   // sync + accumulate pending events
+void hdem_fourier_release(hdem_ctx *ctx);
 
 static inline int hdem_check_raster(const void *in, const void *out, int H,
                                     int W)

@@ -7,6 +7,12 @@ Reference twins (`cguerrero/hydrodem/filters/custom_filters.py`):
 ``PostProcessingFinal`` :1104-1125 -- same class names, constructor
 signatures, mutable operand attributes and error classes.
 
+Fourier destripe branch: ``ExpandFilter`` :76-125,
+``IsolatedPoints`` :320-366, ``BlanksFourier`` :369-429,
+``DetectBlanksFourier`` :432-462, ``MaskFourier`` :537-561, ``FourierInitial``
+:834-877, ``FourierProcessQuarters`` :880-1050, ``DetectApplyFourier``
+:1053-1101.
+
 New operators (the reference has neither): ``SinkFill`` and
 ``D8FlowDirection``, shaped like every other ``Filter``.
 
@@ -19,10 +25,11 @@ anyway (`sliding_window.py:132`).
 
 import numpy as np
 
-from . import Filter, ComposedFilter
+from . import Filter, ComposedFilter, ComposedFilterResults
 from .simple_filters import (GreaterThan, BooleanToInteger, ProductFilter,
                              SubtractionFilter)
-from .extension_filters import Convolve, Around
+from .extension_filters import (Convolve, Around, AbsoluteValues, FourierTransform,
+                                FourierShift)
 from .. import backend
 
 
@@ -236,3 +243,150 @@ class HydroConditioning(ComposedFilter):  # pylint: disable=too-few-public-metho
                     filled.ctx.synchronize()
                     self.filled = filled.to_host()
                     return codes.to_host()
+
+
+# ---------------------------------------------------------------------------
+# Fourier destripe
+# ---------------------------------------------------------------------------
+class ExpandFilter(Filter):  # pylint: disable=too-few-public-methods
+    """1 at the centres whose ``window_size`` square minus its four corners holds a
+    cell > 0, 0 elsewhere -- including the ring of ``window_size // 2`` cells where
+    the window does not fit (custom_filters.py:76-125)."""
+
+    def __init__(self, *, window_size):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        return backend.expand(image_to_filter, self.window_size).astype(np.float64)
+
+
+class IsolatedPoints(Filter):  # pylint: disable=too-few-public-methods
+    """Cells equal to 1 with no other cell > 0 in their window become 0; like the
+    reference (custom_filters.py:320-366) this writes into its input and returns
+    it.  Only centres whose window fits are looked at."""
+
+    def __init__(self, *, window_size):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        img = image_to_filter
+        g = np.asarray(img, dtype=np.float32)                # the window snapshot
+        ones = np.trunc(g) == 1
+        code = np.where(ones, 1, np.where(g > 0, 2, 0)).astype(np.uint8)
+        res = backend.isolated_points(code, self.window_size)
+        r = self.window_size // 2
+        inner = np.zeros(g.shape, dtype=bool)
+        inner[r:g.shape[0] - r, r:g.shape[1] - r] = True
+        sel = ones & inner
+        img[sel] = res[sel].astype(img.dtype)
+        return img
+
+
+class BlanksFourier(Filter):  # pylint: disable=too-few-public-methods
+    """Peaks of a spectrum magnitude: cells above 4x the mean of their 55 x 55
+    neighbourhood, its inner 5 x 5 and everything past the array edge left out.
+    Returns (mask, image with the peaks zeroed) (custom_filters.py:369-429).
+    The kernel is built for the one window the reference uses, 55."""
+
+    def __init__(self, *, window_size):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        if self.window_size != 55:
+            raise NotImplementedError("BlanksFourier is built for window_size=55 "
+                                      "(the only value the reference uses)")
+        return backend.blanks_fourier(image_to_filter)
+
+
+class DetectBlanksFourier(Filter):  # pylint: disable=too-few-public-methods
+    """Two ``BlanksFourier`` passes, the second on the image without the first
+    pass's peaks; the masks are added (custom_filters.py:432-462)."""
+
+    def apply(self, quarter_fourier):
+        total = np.zeros(np.shape(quarter_fourier))
+        blanks = BlanksFourier(window_size=55)
+        for _ in (0, 1):
+            found, quarter_fourier = blanks.apply(quarter_fourier)
+            total += found
+        return total
+
+
+class MaskFourier(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """detect -> drop isolated points -> expand (custom_filters.py:537-561)."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [DetectBlanksFourier(), IsolatedPoints(window_size=3),
+                        ExpandFilter(window_size=13)]
+
+
+class FourierInitial(ComposedFilterResults):  # pylint: disable=too-few-public-methods
+    """fft2 -> fftshift -> abs; keeps the shifted spectrum
+    (custom_filters.py:834-877)."""
+
+    def __init__(self):
+        super().__init__()
+        self.filters = [FourierTransform(), FourierShift(), AbsoluteValues()]
+        self.fourier_shift = None
+
+    def apply(self, image_to_filter):
+        result = super().apply(image_to_filter)
+        self.fourier_shift = self.results["FourierShift"]
+        return result
+
+
+class FourierProcessQuarters(Filter):  # pylint: disable=too-few-public-methods
+    """Mask of the frequencies to drop, from the magnitude of the shifted
+    spectrum: ``MaskFourier`` on the two upper quadrants (10-cell margin to the
+    axes), point-mirrored into the lower half (custom_filters.py:880-1050).
+    ``apply`` ignores its argument, as the reference does."""
+
+    def __init__(self, fft_transform_abs):
+        self.fft_transform_abs = fft_transform_abs
+        self._ny, self._nx = fft_transform_abs.shape
+        self._mid_y, self._y_odd = divmod(self._ny, 2)
+        self._mid_x, self._x_odd = divmod(self._nx, 2)
+        self.pair_mid = self._mid_y, self._mid_x
+        self._margin = 10
+
+    def apply(self, image_to_filter):  # pylint: disable=unused-argument
+        ny, nx, my, mx, m = self._ny, self._nx, self._mid_y, self._mid_x, self._margin
+        mag = self.fft_transform_abs
+        first = MaskFourier().apply(np.array(mag[:my - m, :mx - m]))
+        second = MaskFourier().apply(np.array(mag[:my - m, mx + m + self._x_odd:nx]))
+        q1 = np.zeros(self.pair_mid)
+        q2 = np.zeros(self.pair_mid)
+        q1[:my - m, :mx - m] = first
+        q2[:my - m, m:mx] = second
+        full = np.zeros((ny, nx))
+        full[:my, :mx] = q1
+        full[:my, mx + self._x_odd:] = q2
+        full[my + self._y_odd:, :mx] = q2[::-1, ::-1]
+        full[my + self._y_odd:, mx + self._x_odd:] = q1[::-1, ::-1]
+        return full
+
+
+class DetectApplyFourier(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """Destripe: find the bright isolated frequencies of the spectrum, zero them,
+    transform back (custom_filters.py:1053-1101).  One device-resident pass
+    (``hdem_fourier_destripe_f32``): the shifts are index maps, the quadrant masks
+    are applied straight to the spectrum.  Returns float32 (the reference: float64
+    from a complex128 inverse; values agree to ~1e-5 m).  With
+    ``keep_mask=True`` the full mask is kept in ``.mask`` afterwards."""
+
+    def __init__(self, keep_mask=False):  # pylint: disable=super-init-not-called
+        self.initial = FourierInitial()
+        self.fft_transform_abs = None
+        self.keep_mask = keep_mask
+        self.mask = None
+        self.filters = []
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        if self.keep_mask:
+            out, mask = backend.fourier_destripe(image_to_filter, return_mask=True)
+            self.mask = mask.astype(np.float64)
+            return out
+        return backend.fourier_destripe(image_to_filter)
+
+    def apply_device(self, raster):
+        return backend.fourier_destripe_dev(raster)

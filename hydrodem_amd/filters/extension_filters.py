@@ -1,11 +1,18 @@
 """
-The two SciPy/NumPy wrapper filters that sit on the named path, backed by HIP
-kernels: ``Convolve`` and ``Around``
-(`cguerrero/hydrodem/filters/extension_filters.py:133-184,98-130`).
+The SciPy/NumPy wrapper filters of the built paths, backed by the HIP library:
+``Convolve`` and ``Around`` (`cguerrero/hydrodem/filters/extension_filters.py:
+133-184,98-130`) and, for the Fourier destripe branch,
+``AbsoluteValues`` :63-95, ``FourierTransform`` / ``FourierITransform`` /
+``FourierShift`` / ``FourierIShift`` :348-480.
 
-The other wrappers of that module (morphology, XOR, FFT) belong to the
-lagoon/river and Fourier branches, which are outside this build's scope
-(SURVEY section 8f); they are not re-declared here.
+The transforms run on the GPU (rocFFT) in complex64 -- what scipy.fftpack
+returns for the float32 rasters of the pipeline; for other input types the
+reference would compute in double.  The shifts and the absolute value are data
+movement / one NumPy expression on the host; inside ``DetectApplyFourier`` none
+of them is executed as a separate step (index maps in the kernels).
+
+The morphology / XOR wrappers belong to the lagoon and river branches, which are
+outside this build's scope; they are not re-declared here.
 """
 
 import numpy as np
@@ -51,3 +58,44 @@ class Convolve(Filter):  # pylint: disable=too-few-public-methods
             raise NotImplementedError(
                 "device-resident Convolve supports the 3x3 ones() weights")
         return backend.boxmean3_dev(raster, do_round=False)
+
+
+class AbsoluteValues(Filter):  # pylint: disable=too-few-public-methods
+    """``np.absolute`` (extension_filters.py:63-95)."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return np.absolute(image_to_filter)
+
+
+class FourierTransform(Filter):  # pylint: disable=too-few-public-methods
+    """2-D discrete Fourier transform (extension_filters.py:348-379)."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return backend.fft2(image_to_filter)
+
+
+class FourierITransform(Filter):  # pylint: disable=too-few-public-methods
+    """Inverse 2-D transform, normalised by the size
+    (extension_filters.py:382-414)."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return backend.fft2(image_to_filter, inverse=True)
+
+
+class FourierShift(Filter):  # pylint: disable=too-few-public-methods
+    """Zero frequency to the centre (extension_filters.py:417-447)."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return np.fft.fftshift(image_to_filter)
+
+
+class FourierIShift(Filter):  # pylint: disable=too-few-public-methods
+    """Inverse of :class:`FourierShift` (extension_filters.py:450-480)."""
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return np.fft.ifftshift(image_to_filter)

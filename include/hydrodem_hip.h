@@ -72,7 +72,12 @@ typedef enum hdem_kernel_id {
     HDEM_K_FILL_SCAN = 6,     /* (reserved)                                 */
     HDEM_K_FILL_ROUND = 7,    /* round-synchronous certifying / finishing pass */
     HDEM_K_BLOCKMAX = 8,      /* block-maximum coarsening (multi-GPU start values) */
-    HDEM_K_COUNT = 9
+    HDEM_K_FFT = 9,           /* rocFFT 2-D complex transform (forward or inverse) */
+    HDEM_K_FOURIER_ROWSUM = 10, /* hollow mean, row pass                       */
+    HDEM_K_FOURIER_DETECT = 11, /* hollow mean, column pass + peak decision    */
+    HDEM_K_FOURIER_MASK = 12,   /* isolated points, expand, apply to spectrum  */
+    HDEM_K_FOURIER_POINT = 13,  /* real->complex, |F| of a quadrant, |f|/N     */
+    HDEM_K_COUNT = 14
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -152,6 +157,33 @@ int hdem_set_fill_slice_us(hdem_ctx *ctx, int microseconds);
  * sink fill of z from above cell by cell -- the multi-GPU path uses it as the start value
  * of the ghost rows (new work; the reference is single process). */
 int hdem_blockmax_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, int b, float *out);
+
+/* ---- A8  Fourier destripe ------------------------------------
+ * DetectApplyFourier.apply, custom_filters.py:1083-1101, with FourierInitial
+ * (:834-877), FourierProcessQuarters (:880-1050) and MaskFourier (:537-561)
+ * inside: out = | ifft2( (1 - mask) * fft2(dem) ) |, the mask found on the
+ * magnitude of the two upper quadrants of the shifted spectrum.  float32 /
+ * complex64 throughout (scipy.fftpack keeps float32 input single; the reference
+ * then drifts to complex128 for the inverse: values agree to ~1e-5 m).
+ * mask (optional, H*W bytes): the reference's masks_fourier in shifted
+ * coordinates.  Quadrants smaller than the 55-cell window give
+ * HDEM_ERR_WINDOW_HIGH, as the reference's window constructor does. */
+int hdem_fourier_destripe_f32(hdem_ctx *ctx, const float *dem, int H, int W,
+                              float *out, uint8_t *mask);
+int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W,
+                                  float *out, uint8_t *mask);
+/* BlanksFourier.apply (:400-429), window 55, inner 5, factor 4: found[i] = 1
+ * where q > 4 x hollow mean; q is rewritten as q * (1 - found). */
+int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, uint8_t *found);
+/* IsolatedPoints.apply (:344-366) and ExpandFilter.apply (:103-125) on byte masks. */
+int hdem_isolated_points_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w,
+                                int window, uint8_t *out);
+int hdem_expand_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w, int window,
+                       uint8_t *out);
+/* FourierTransform / FourierITransform (extension_filters.py:348-414) on an
+ * interleaved complex64 H x W array, in place; the inverse is unnormalised
+ * (scipy's ifft2 = this / (H*W)). */
+int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, int inverse);
 
 /* ---- A5  Convolve.apply + Around.apply -----------------------------------
  * extension_filters.py:166-184 (scipy.ndimage.convolve, mode='reflect',
