@@ -93,6 +93,40 @@ def cpu_baseline(z_crop):
                                          "(a better CPU algorithm than the NumPy path)"}}
 
 
+def filter_paths(B, ctx, zd, scratch, S, reps=3):
+    """The other operators of the scope table on the same raster, outside the timed
+    region (they are not part of the headline metric): warm call, then ``reps`` timed."""
+    import oracle
+    res = {}
+
+    def timed(fn):
+        fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        return {"ms": ms, "Mcells_per_s": S * S / ms / 1e3}
+
+    mask = B.DeviceRaster.from_host(oracle.synth_groves(S, S), ctx=ctx)
+    res["groves_x3"] = dict(timed(lambda: B.groves_dev(zd, mask, iterations=3, out=scratch)),
+                            algorithmic_bytes_per_cell=27)
+    mask.free()
+    res["boxmean3_round"] = dict(timed(lambda: B.boxmean3_dev(zd, out=scratch)),
+                                 algorithmic_bytes_per_cell=8)
+    ctx.profile(True)
+    ctx.profile_reset()
+    res["fourier_destripe"] = timed(lambda: B.fourier_destripe_dev(zd, out=scratch))
+    n_calls = reps + 1
+    for name, kid in (("rocfft_c2c", B.K_FFT), ("rowsum", B.K_FOURIER_ROWSUM),
+                      ("detect", B.K_FOURIER_DETECT), ("mask", B.K_FOURIER_MASK),
+                      ("pointwise", B.K_FOURIER_POINT)):
+        res["fourier_destripe"][name + "_ms"] = ctx.profile_get(kid)["ms"] / n_calls
+    ctx.profile(False)
+    return res
+
+
 def main():
     a = parse()
     S, N = a.size, a.gpus
@@ -226,6 +260,8 @@ def main():
                             "note": "certifying pass: 1 launch with work + 7 empty per step"},
                         "fill_init_kernel": {"avg_launch_ms": ki["ms"] / max(ki["launches"], 1)}},
         }
+        if N == 1:
+            out["filters"] = filter_paths(B, ctx, zd, wd, S)
         if a.cpu_sample and N == 1:
             c = min(a.cpu_sample, S)
             zc = np.ascontiguousarray(z[:c, :c])
