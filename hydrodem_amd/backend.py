@@ -423,11 +423,22 @@ def quadratic_dev(dem, window_size=15, out=None):
     return out
 
 
-def groves_dev(img, groves, window_size=15, threshold=1.5, iterations=3, out=None):
+def groves_dev(img, groves, window_size=15, threshold=1.5, iterations=3, out=None,
+               scratch=None):
+    """``scratch``: a float32 raster of the same shape for the ping-pong between
+    passes (allocated and freed here when not given)."""
     _need(img, np.float32)
     _need(groves, np.uint8)
     c = img.ctx
     out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    if scratch is not None:
+        _need(scratch, np.float32)
+        c.check(c.lib.hdem_groves_f32_dev(c.handle, img.ptr, groves.ptr, img.shape[0],
+                                          img.shape[1], int(window_size),
+                                          float(threshold), int(iterations),
+                                          scratch.ptr, out.ptr),
+                window=window_size, shape=img.shape)
+        return out
     scratch = DeviceRaster.empty(img.shape, np.float32, c) if iterations > 1 else None
     try:
         c.check(c.lib.hdem_groves_f32_dev(c.handle, img.ptr, groves.ptr, img.shape[0],
