@@ -127,6 +127,22 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
                       ("pointwise", B.K_FOURIER_POINT)):
         res["fourier_destripe"][name + "_ms"] = ctx.profile_get(kid)["ms"] / n_calls
     ctx.profile(False)
+    # lagoon branch on the integer-metre variant of the raster with voids
+    hs = np.round(zd.to_host())
+    hs[::97, ::89] = -32768.0
+    hd_ = B.DeviceRaster.from_host(hs, ctx=ctx)
+    del hs
+    ctx.profile(True)
+    ctx.profile_reset()
+
+    def lagoons():
+        for r in B.lagoons_detection_dev(hd_):
+            r.free()
+    res["lagoons_detection"] = timed(lagoons)
+    res["lagoons_detection"]["majority_ms"] = ctx.profile_get(B.K_MAJORITY)["ms"] / n_calls
+    res["lagoons_detection"]["other_kernels_ms"] = ctx.profile_get(B.K_LAGOON)["ms"] / n_calls
+    ctx.profile(False)
+    hd_.free()
     return res
 
 

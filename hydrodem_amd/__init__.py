@@ -24,10 +24,13 @@ from .filters.custom_filters import (QuadraticFilter, MaskTallGroves,  # noqa: F
                                      D8FlowDirection, HydroConditioning,
                                      ExpandFilter, IsolatedPoints, BlanksFourier,
                                      DetectBlanksFourier, MaskFourier, FourierInitial,
-                                     FourierProcessQuarters, DetectApplyFourier)
+                                     FourierProcessQuarters, DetectApplyFourier,
+                                     MajorityFilter, CorrectNANValues, MaskNegatives,
+                                     MaskPositives, TidyingLagoons, LagoonsDetection)
 from .filters.extension_filters import (Convolve, Around, AbsoluteValues,  # noqa: F401
                                         FourierTransform, FourierITransform,
-                                        FourierShift, FourierIShift)
+                                        FourierShift, FourierIShift, BitwiseXOR,
+                                        BinaryErosion, BinaryClosing, GreyDilation)
 from .filters.simple_filters import (LowerThan, GreaterThan, BooleanToInteger,  # noqa: F401
                                      ProductFilter, AdditionFilter,
                                      SubtractionFilter)

@@ -27,6 +27,7 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 # kernel ids for the timing query
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
 K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
+K_LAGOON, K_MAJORITY = 14, 15
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
@@ -81,6 +82,13 @@ SIGNATURES = {
     "hdem_isolated_points_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_expand_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_fft2_c2c_f32_dev": [_vp, _vp, _i, _i, _i],
+    "hdem_correct_nan_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_majority_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_binary_erosion_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp],
+    "hdem_binary_closing_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "hdem_grey_dilation_f32_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "hdem_tidying_lagoons_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_lagoons_detection_f32_dev": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "hdem_boxmean3_f32": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f64": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
@@ -400,6 +408,100 @@ def fft2_dev(data, inverse=False):
     c.check(c.lib.hdem_fft2_c2c_f32_dev(c.handle, data.ptr, data.shape[0], data.shape[1],
                                         int(bool(inverse))))
     return data
+
+
+def correct_nan_dev(dem, out=None):
+    _need(dem, np.float32)
+    c = dem.ctx
+    out = out or DeviceRaster.empty(dem.shape, np.float32, c)
+    c.check(c.lib.hdem_correct_nan_f32_dev(c.handle, dem.ptr, dem.shape[0], dem.shape[1],
+                                           out.ptr), window=3, shape=dem.shape)
+    return out
+
+
+def majority_dev(img, window_size=11, out=None):
+    _need(img, np.float32)
+    c = img.ctx
+    out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    c.check(c.lib.hdem_majority_f32_dev(c.handle, img.ptr, img.shape[0], img.shape[1],
+                                        int(window_size), out.ptr),
+            window=window_size, shape=img.shape)
+    return out
+
+
+def _structure_arg(structure):
+    if structure is None:
+        return None, 0, 0, None
+    st = np.ascontiguousarray(np.asarray(structure) != 0, dtype=np.uint8)
+    if st.ndim != 2:
+        raise ValueError(f"expected a 2-D structure, got shape {st.shape}")
+    return st.ctypes.data, st.shape[0], st.shape[1], st
+
+
+def binary_erosion_dev(mask, iterations=1, structure=None, out=None):
+    _need(mask, np.uint8)
+    c = mask.ctx
+    out = out or DeviceRaster.empty(mask.shape, np.uint8, c)
+    tmp = DeviceRaster.empty(mask.shape, np.uint8, c) if iterations > 1 else None
+    ptr, sh, sw, keep = _structure_arg(structure)
+    try:
+        c.check(c.lib.hdem_binary_erosion_u8_dev(c.handle, mask.ptr, mask.shape[0],
+                                                 mask.shape[1], ptr, sh, sw, int(iterations),
+                                                 tmp.ptr if tmp else None, out.ptr))
+    finally:
+        if tmp is not None:
+            c.synchronize()
+            tmp.free()
+    del keep
+    return out
+
+
+def binary_closing_dev(mask, structure=None, out=None):
+    _need(mask, np.uint8)
+    c = mask.ctx
+    out = out or DeviceRaster.empty(mask.shape, np.uint8, c)
+    tmp = DeviceRaster.empty(mask.shape, np.uint8, c)
+    ptr, sh, sw, keep = _structure_arg(structure)
+    try:
+        c.check(c.lib.hdem_binary_closing_u8_dev(c.handle, mask.ptr, mask.shape[0],
+                                                 mask.shape[1], ptr, sh, sw, tmp.ptr, out.ptr))
+    finally:
+        c.synchronize()
+        tmp.free()
+    del keep
+    return out
+
+
+def grey_dilation_dev(img, size, out=None):
+    _need(img, np.float32)
+    c = img.ctx
+    out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    sy, sx = (size, size) if np.isscalar(size) else size
+    c.check(c.lib.hdem_grey_dilation_f32_dev(c.handle, img.ptr, img.shape[0], img.shape[1],
+                                             int(sy), int(sx), out.ptr))
+    return out
+
+
+def tidying_lagoons_dev(img, out=None):
+    _need(img, np.float32)
+    c = img.ctx
+    out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    c.check(c.lib.hdem_tidying_lagoons_f32_dev(c.handle, img.ptr, img.shape[0], img.shape[1],
+                                               out.ptr), window=7, shape=img.shape)
+    return out
+
+
+def lagoons_detection_dev(hsheds):
+    """(mask uint8, hsheds_nan_fixed, lagoons_values) device rasters."""
+    _need(hsheds, np.float32)
+    c = hsheds.ctx
+    fixed = DeviceRaster.empty(hsheds.shape, np.float32, c)
+    values = DeviceRaster.empty(hsheds.shape, np.float32, c)
+    mask = DeviceRaster.empty(hsheds.shape, np.uint8, c)
+    c.check(c.lib.hdem_lagoons_detection_f32_dev(c.handle, hsheds.ptr, hsheds.shape[0],
+                                                 hsheds.shape[1], fixed.ptr, values.ptr,
+                                                 mask.ptr), window=11, shape=hsheds.shape)
+    return mask, fixed, values
 
 
 def boxmean3_dev(x, do_round=True, out=None):

@@ -13,6 +13,10 @@ Fourier destripe branch: ``ExpandFilter`` :76-125,
 :834-877, ``FourierProcessQuarters`` :880-1050, ``DetectApplyFourier``
 :1053-1101.
 
+Lagoon branch: ``MajorityFilter`` :22-73, ``CorrectNANValues``
+:260-317, ``MaskNegatives`` / ``MaskPositives`` :465-510, ``TidyingLagoons``
+:564-610, ``LagoonsDetection`` :613-661.
+
 New operators (the reference has neither): ``SinkFill`` and
 ``D8FlowDirection``, shaped like every other ``Filter``.
 
@@ -26,10 +30,10 @@ anyway (`sliding_window.py:132`).
 import numpy as np
 
 from . import Filter, ComposedFilter, ComposedFilterResults
-from .simple_filters import (GreaterThan, BooleanToInteger, ProductFilter,
+from .simple_filters import (GreaterThan, LowerThan, BooleanToInteger, ProductFilter,
                              SubtractionFilter)
 from .extension_filters import (Convolve, Around, AbsoluteValues, FourierTransform,
-                                FourierShift)
+                                FourierShift, BinaryErosion, GreyDilation)
 from .. import backend
 
 
@@ -390,3 +394,124 @@ class DetectApplyFourier(ComposedFilter):  # pylint: disable=too-few-public-meth
 
     def apply_device(self, raster):
         return backend.fourier_destripe_dev(raster)
+
+
+# ---------------------------------------------------------------------------
+# HydroSHEDS / lagoon branch
+# ---------------------------------------------------------------------------
+class MajorityFilter(Filter):  # pylint: disable=too-few-public-methods
+    """The value that fills more than 70 % of ``window_size**2 - 1`` cells of the
+    circular window (square minus corners, the centre counts), else 0; the ring
+    where the window does not fit stays 0 (custom_filters.py:22-73)."""
+
+    def __init__(self, *, window_size):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        img = backend.DeviceRaster.from_host(
+            np.ascontiguousarray(image_to_filter, dtype=np.float32))
+        return backend.majority_dev(img, self.window_size).to_host().astype(np.float64)
+
+    def apply_device(self, raster):
+        return backend.majority_dev(raster, self.window_size)
+
+
+class CorrectNANValues(Filter):  # pylint: disable=too-few-public-methods
+    """Voids (cells < 0) become the mean of their non-negative neighbours; like the
+    reference (custom_filters.py:260-317) this writes into its input and returns
+    it.  Built for the 3 x 3 window the reference uses."""
+
+    def __init__(self, *, window_size=3):
+        self.window_size = window_size
+
+    def apply(self, image_to_filter):
+        if self.window_size != 3:
+            raise NotImplementedError("CorrectNANValues is built for window_size=3 "
+                                      "(the only value the reference uses)")
+        dem = image_to_filter
+        g = np.ascontiguousarray(dem, dtype=np.float32)
+        fixed = backend.correct_nan_dev(backend.DeviceRaster.from_host(g)).to_host()
+        sel = np.zeros(g.shape, dtype=bool)
+        sel[1:-1, 1:-1] = g[1:-1, 1:-1] < 0
+        dem[sel] = fixed[sel]
+        return dem
+
+    def apply_device(self, raster):
+        return backend.correct_nan_dev(raster)
+
+
+class MaskNegatives(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """1 where the image is negative (custom_filters.py:465-487)."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [LowerThan(value=0.0), BooleanToInteger()]
+
+
+class MaskPositives(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """1 where the image is positive (custom_filters.py:490-510)."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [GreaterThan(value=0.0), BooleanToInteger()]
+
+
+class TidyingLagoons(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """Erode twice, expand by 7, multiply with the input, 7 x 7 grey dilation
+    (custom_filters.py:564-610).  ``apply`` runs the four steps in one
+    device-resident call when the list is the stock one; ``filters`` stays
+    inspectable and patchable like the reference's."""
+
+    def __init__(self):  # pylint: disable=super-init-not-called
+        self.filters = [BinaryErosion(iterations=2), ExpandFilter(window_size=7),
+                        ProductFilter(), GreyDilation(size=(7, 7))]
+
+    def _stock(self):
+        f = self.filters
+        return (len(f) == 4 and isinstance(f[0], BinaryErosion) and f[0].iterations == 2 and
+                isinstance(f[1], ExpandFilter) and f[1].window_size == 7 and
+                isinstance(f[2], ProductFilter) and isinstance(f[3], GreyDilation) and
+                tuple(np.atleast_1d(f[3].size)) in ((7, 7), (7,)))
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        self.filters[2].factor = content = image_to_filter
+        if self._stock():
+            img = backend.DeviceRaster.from_host(
+                np.ascontiguousarray(image_to_filter, dtype=np.float32))
+            return backend.tidying_lagoons_dev(img).to_host().astype(np.float64)
+        for filter_ in self.filters:
+            content = filter_.apply(content)
+        return content
+
+    def apply_device(self, raster):
+        return backend.tidying_lagoons_dev(raster)
+
+
+class LagoonsDetection(ComposedFilterResults):  # pylint: disable=too-few-public-methods
+    """NaN repair -> majority (11) -> tidying -> mask of positives, keeping the
+    intermediate results the orchestration reads (custom_filters.py:613-661).
+    One device-resident call (``hdem_lagoons_detection_f32_dev``); like the
+    reference the void repair is also written into the input array."""
+
+    def __init__(self):
+        super().__init__()
+        self.filters = [CorrectNANValues(), MajorityFilter(window_size=11),
+                        TidyingLagoons(), MaskPositives()]
+        self.hsheds_nan_fixed = None
+        self.mask_lagoons = None
+        self.lagoons_values = None
+
+    def apply(self, image_to_filter):
+        Filter.apply(self, image_to_filter)
+        g = np.ascontiguousarray(image_to_filter, dtype=np.float32)
+        mask, fixed, values = backend.lagoons_detection_dev(backend.DeviceRaster.from_host(g))
+        fixed_h = fixed.to_host()
+        sel = np.zeros(g.shape, dtype=bool)
+        sel[1:-1, 1:-1] = g[1:-1, 1:-1] < 0
+        image_to_filter[sel] = fixed_h[sel]                 # CorrectNANValues works in place
+        self.hsheds_nan_fixed = image_to_filter
+        self.lagoons_values = values.to_host().astype(np.float64)
+        self.mask_lagoons = mask.to_host().astype(np.int64)
+        self.results = {"CorrectNANValues": self.hsheds_nan_fixed,
+                        "TidyingLagoons": self.lagoons_values,
+                        "MaskPositives": self.mask_lagoons}
+        return self.mask_lagoons

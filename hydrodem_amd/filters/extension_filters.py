@@ -11,9 +11,14 @@ reference would compute in double.  The shifts and the absolute value are data
 movement / one NumPy expression on the host; inside ``DetectApplyFourier`` none
 of them is executed as a separate step (index maps in the kernels).
 
-The morphology / XOR wrappers belong to the lagoon and river branches, which are
-outside this build's scope; they are not re-declared here.
+Lagoon branch: ``BinaryErosion`` :187-235, ``BinaryClosing``
+:238-293, ``GreyDilation`` :296-345 (scipy.ndimage semantics: cross structure by
+default, border value 0, ``mode='reflect'`` for the grey dilation; centred odd
+structures / sizes) and ``BitwiseXOR`` :12-60.
 """
+
+import copy
+
 
 import numpy as np
 
@@ -99,3 +104,62 @@ class FourierIShift(Filter):  # pylint: disable=too-few-public-methods
     def apply(self, image_to_filter):
         super().apply(image_to_filter)
         return np.fft.ifftshift(image_to_filter)
+
+
+class BitwiseXOR(Filter):  # pylint: disable=too-few-public-methods
+    """``np.bitwise_xor(operand, image)``; the operand is deep-copied at
+    construction (extension_filters.py:12-60)."""
+
+    def __init__(self, *, operand):
+        self.operand = copy.deepcopy(operand)
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        return np.bitwise_xor(self.operand, image_to_filter)
+
+
+def _mask_raster(image):
+    return backend.DeviceRaster.from_host(
+        np.ascontiguousarray(np.asarray(image) != 0, dtype=np.uint8))
+
+
+class BinaryErosion(Filter):  # pylint: disable=too-few-public-methods
+    """``scipy.ndimage.binary_erosion(image, iterations=...)`` -> bool grid
+    (extension_filters.py:187-235)."""
+
+    def __init__(self, *, iterations):
+        self.iterations = iterations
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        out = backend.binary_erosion_dev(_mask_raster(image_to_filter), self.iterations)
+        return out.to_host().astype(bool)
+
+
+class BinaryClosing(Filter):  # pylint: disable=too-few-public-methods
+    """``scipy.ndimage.binary_closing(image, structure=...)`` -> bool grid
+    (extension_filters.py:238-293)."""
+
+    def __init__(self, *, structure=None):
+        self.structure = structure
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        out = backend.binary_closing_dev(_mask_raster(image_to_filter), self.structure)
+        return out.to_host().astype(bool)
+
+
+class GreyDilation(Filter):  # pylint: disable=too-few-public-methods
+    """``scipy.ndimage.grey_dilation(image, size=...)``: flat maximum filter
+    (extension_filters.py:296-345).  Computed on the float32 values; returned in
+    the input's dtype."""
+
+    def __init__(self, *, size):
+        self.size = size
+
+    def apply(self, image_to_filter):
+        super().apply(image_to_filter)
+        img = backend.DeviceRaster.from_host(np.ascontiguousarray(image_to_filter,
+                                                                  dtype=np.float32))
+        return backend.grey_dilation_dev(img, self.size).to_host().astype(
+            image_to_filter.dtype, copy=False)

@@ -77,7 +77,9 @@ typedef enum hdem_kernel_id {
     HDEM_K_FOURIER_DETECT = 11, /* hollow mean, column pass + peak decision    */
     HDEM_K_FOURIER_MASK = 12,   /* isolated points, expand, apply to spectrum  */
     HDEM_K_FOURIER_POINT = 13,  /* real->complex, |F| of a quadrant, |f|/N     */
-    HDEM_K_COUNT = 14
+    HDEM_K_LAGOON = 14,         /* lagoon branch: NaN repair, morphology, dilation */
+    HDEM_K_MAJORITY = 15,       /* majority vote over the circular window       */
+    HDEM_K_COUNT = 16
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -184,6 +186,35 @@ int hdem_expand_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w, int win
  * interleaved complex64 H x W array, in place; the inverse is unnormalised
  * (scipy's ifft2 = this / (H*W)). */
 int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, int inverse);
+
+/* ---- SURVEY 8f-3  HydroSHEDS / lagoon branch --------------------------------
+ * CorrectNANValues.apply (custom_filters.py:287-317, window 3): interior cells < 0
+ * <- float32 mean of their neighbours >= 0 (NaN when there is none). */
+int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W, float *out);
+/* MajorityFilter.apply (:44-73): value held by > 70 % of (window^2 - 1) cells of the
+ * window minus its corners, else 0; window odd, 3..15. */
+int hdem_majority_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int window,
+                          float *out);
+/* scipy.ndimage.binary_erosion(iterations) / binary_closing(structure)
+ * (extension_filters.py:187-293): byte masks, border_value 0; structure = sh x sw bytes,
+ * odd sizes up to 7, NULL = the 3 x 3 cross.  tmp: a scratch mask of the same size
+ * (may be NULL for a single erosion). */
+int hdem_binary_erosion_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int H, int W,
+                               const uint8_t *structure, int sh, int sw, int iterations,
+                               uint8_t *tmp, uint8_t *out);
+int hdem_binary_closing_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int H, int W,
+                               const uint8_t *structure, int sh, int sw, uint8_t *tmp,
+                               uint8_t *out);
+/* scipy.ndimage.grey_dilation(size=(sy, sx)) (extension_filters.py:296-345): flat
+ * maximum filter, mode 'reflect', odd sizes. */
+int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int sy, int sx,
+                               float *out);
+/* TidyingLagoons.apply (:564-610) and LagoonsDetection.apply (:613-661), device
+ * resident.  fixed / values (may be NULL): the reference's hsheds_nan_fixed and
+ * lagoons_values; mask: 1 where lagoons_values > 0. */
+int hdem_tidying_lagoons_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, float *out);
+int hdem_lagoons_detection_f32_dev(hdem_ctx *ctx, const float *hsheds, int H, int W,
+                                   float *fixed, float *values, uint8_t *mask);
 
 /* ---- A5  Convolve.apply + Around.apply -----------------------------------
  * extension_filters.py:166-184 (scipy.ndimage.convolve, mode='reflect',
