@@ -132,6 +132,43 @@ extern "C" int hdem_memcpy_d2h(hdem_ctx *c, void *d, const void *s, size_t n)
 extern "C" int hdem_memcpy_d2d(hdem_ctx *c, void *d, const void *s, size_t n)
 { return copy_sync(c, d, s, n, hipMemcpyDeviceToDevice); }
 
+// Pinned host memory and stream-ordered copies: the raster I/O seam.  A
+// caller that reads a raster band by band (GDAL ReadAsArray of windows) reads straight
+// into a pinned buffer, queues copy -> kernels -> copy on this context's stream and goes
+// on to the next band on another context; hdem_synchronize() is the only wait.
+extern "C" int hdem_host_alloc(hdem_ctx *ctx, size_t bytes, void **hptr)
+{
+    HDEM_REQUIRE(ctx && hptr, HDEM_ERR_BAD_ARG, "null argument");
+    *hptr = nullptr;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_host_free(hdem_ctx *ctx, void *hptr)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (!hptr) return HDEM_OK;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HDEM_HIP_CHECK(hipHostFree(hptr));
+    return HDEM_OK;
+}
+
+static int copy_async(hdem_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    HDEM_REQUIRE(ctx && (bytes == 0 || (dst && src)), HDEM_ERR_BAD_ARG, "null argument");
+    if (!bytes) return HDEM_OK;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_memcpy_h2d_async(hdem_ctx *c, void *d, const void *s, size_t n)
+{ return copy_async(c, d, s, n, hipMemcpyHostToDevice); }
+extern "C" int hdem_memcpy_d2h_async(hdem_ctx *c, void *d, const void *s, size_t n)
+{ return copy_async(c, d, s, n, hipMemcpyDeviceToHost); }
+
 // ---------------------------------------------------------------------------
 // profiling
 // ---------------------------------------------------------------------------

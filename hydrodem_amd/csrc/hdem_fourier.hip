@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <mutex>
 
 #include "hdem_internal.h"
 
@@ -51,9 +52,11 @@ struct rocfft_api {
 };
 
 rocfft_api g_fft;
+std::mutex g_fft_lock;      // contexts of different threads may get here together
 
 int load_rocfft()
 {
+    std::lock_guard<std::mutex> guard(g_fft_lock);
     if (g_fft.handle) return HDEM_OK;
     const char *names[] = {"librocfft.so.0", "/opt/rocm/lib/librocfft.so.0", "librocfft.so"};
     void *h = nullptr;

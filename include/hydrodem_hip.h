@@ -60,6 +60,14 @@ int hdem_free(hdem_ctx *ctx, void *dptr);
 int hdem_memcpy_h2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2h(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Raster I/O seam (utils_dem.py:17-40 reads / writes whole arrays):
+ * page-locked host buffers and copies ordered on the context's stream, so that a band
+ * of a raster can be read into pinned memory, processed and written back while the
+ * next band is in flight on another context.  hdem_synchronize() waits. */
+int hdem_host_alloc(hdem_ctx *ctx, size_t bytes, void **hptr);
+int hdem_host_free(hdem_ctx *ctx, void *hptr);
+int hdem_memcpy_h2d_async(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+int hdem_memcpy_d2h_async(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 
 /* ---- per-kernel timing (HIP events on the stream the kernels run on) ---- */
 typedef enum hdem_kernel_id {

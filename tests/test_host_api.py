@@ -185,3 +185,11 @@ def test_python_constants_match_the_header():
     # struct layouts the binding mirrors: 6 int32 + 6 int64 / 2 int64 + 1 double
     assert ctypes.sizeof(backend.FillStats) == 80 and backend.FillStats.pending.offset == 72
     assert ctypes.sizeof(backend.KernelStat) == 24
+
+
+def test_band_ranges_cover_the_raster_with_halos():
+    from hydrodem_amd import streaming as S
+    assert S.band_ranges(10, 4, 1) == [(0, 4, 0, 5), (4, 8, 3, 9), (8, 10, 7, 10)]
+    assert S.band_ranges(5, 8, 21) == [(0, 5, 0, 5)]
+    with pytest.raises(ValueError):
+        S.band_ranges(5, 0, 1)
