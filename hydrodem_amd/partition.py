@@ -129,10 +129,12 @@ class HipLocalSolver:
 
 
 def _exchange(dist, torch, w, top, bottom, rank):
-    """Swap boundary rows with the neighbours; returns (top_changed,
-    bottom_changed) as Python bools.  One batched isend/irecv group.  Under the
-    gloo backend device tensors are staged through the host (gloo has no device
-    point-to-point); that is the rehearsal path, RCCL moves device memory."""
+    """Swap boundary rows with the neighbours; returns a 2-element int32 tensor on
+    ``w``'s device, (top_changed, bottom_changed) -- not read back here, so that the
+    caller pays one host synchronisation per exchange for flags and all-reduce
+    together.  One batched isend/irecv group.  Under the gloo backend device tensors
+    are staged through the host (gloo has no device point-to-point); that is the
+    rehearsal path, RCCL moves device memory."""
     ops, recv_top, recv_bot = [], None, None
     h = w.shape[0]
     stage = w.is_cuda and dist.get_backend() == "gloo"
@@ -159,8 +161,19 @@ def _exchange(dist, torch, w, top, bottom, rank):
     if bottom:
         flags[1] = (recv_bot.view(torch.int32) != w[h - 1].view(torch.int32)).any()
         w[h - 1].copy_(recv_bot)
-    f = flags.cpu()
-    return bool(f[0]), bool(f[1])
+    return flags
+
+
+def _exchange_and_vote(dist, torch, w, top, bottom, rank, pending, group):
+    """One halo exchange plus the global "is anybody still busy" vote.  Returns
+    (any rank busy, top ghost changed, bottom ghost changed)."""
+    flags = _exchange(dist, torch, w, top, bottom, rank)
+    busy = (flags.max() + int(pending > 0)).clamp(max=1).reshape(1)
+    if dist.get_backend() == "gloo":
+        busy = busy.cpu()                       # gloo reduces host tensors
+    dist.all_reduce(busy, op=dist.ReduceOp.MAX, group=group)
+    out = torch.cat([busy.to(flags.device), flags]).cpu()          # the one read-back
+    return bool(out[0]), bool(out[1]), bool(out[2])
 
 
 def _all_gather(dist, torch, t, world, group):
@@ -239,16 +252,14 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     visits, _, pending = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY, sliced)
     exchanges = verifications = 0
     while world > 1:
-        ch_top, ch_bot = _exchange(dist, torch, w, top, bottom, rank)
+        any_busy, ch_top, ch_bot = _exchange_and_vote(dist, torch, w, top, bottom, rank,
+                                                      pending, group)
         if flag_dev is None:
             flag_dev = "cpu" if dist.get_backend() == "gloo" else w.device
-        busy = torch.tensor([int(ch_top or ch_bot or pending > 0)], dtype=torch.int32,
-                            device=flag_dev)
-        dist.all_reduce(busy, op=dist.ReduceOp.MAX, group=group)
         exchanges += 1
         if exchanges >= max_exchanges:
             raise RuntimeError("distributed sink fill did not converge")
-        if int(busy.item()) == 0:
+        if not any_busy:
             # every rank is at rest: certify the whole block (round driver, all tiles
             # due); resume only if some rank still found something to lower
             v, lowered, pending = solver.fill(z_local, w, eps,
