@@ -114,8 +114,17 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     res["groves_x3"] = dict(timed(lambda: B.groves_dev(zd, mask, iterations=3, out=scratch,
                                                        scratch=pong)),
                             algorithmic_bytes_per_cell=27)
-    mask.free()
-    pong.free()
+    # BASELINE configs[2]: the full chain -- groves x3, sink fill, D8 -- device resident
+    filled = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
+    codes = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
+
+    def chain():
+        B.groves_dev(zd, mask, iterations=3, out=scratch, scratch=pong)
+        B.sinkfill_dev(scratch, out=filled)
+        B.d8_dev(filled, out=codes)
+    res["full_chain_groves_fill_d8"] = timed(chain)
+    for r in (mask, pong, filled, codes):
+        r.free()
     res["boxmean3_round"] = dict(timed(lambda: B.boxmean3_dev(zd, out=scratch)),
                                  algorithmic_bytes_per_cell=8)
     ctx.profile(True)

@@ -238,9 +238,13 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     // row loads of the lane are in flight together.
     float z[WN], w[WN];
     const int xc = min(x, W - 1);
-    // 32-bit byte offsets: the asynchronous driver is used for rasters below 4 GiB
+    // Buffer instructions take 32-bit byte offsets: the resource is based at the window's
+    // first row (wave-uniform), so offsets stay below 64 rows whatever the raster size.
+    float *wbase = wg + (size_t)y0 * W;
+    const size_t wbytes = (size_t)(H - y0) * W * sizeof(float);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        wg, 0, COHERENT ? (int)(unsigned)((size_t)H * W * sizeof(float)) : 0, 0x00020000);
+        wbase, 0, COHERENT ? (int)(unsigned)(wbytes < 0xffffffffull ? wbytes : 0xffffffffull) : 0,
+        0x00020000);
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
@@ -249,7 +253,8 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
         if (COHERENT)
             w[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                wrsrc, (unsigned)(o * sizeof(float)), 0, AUX_SC1));
+                wrsrc, (unsigned)(((size_t)(min(y0 + r, H - 1) - y0) * W + xc) * sizeof(float)), 0,
+                AUX_SC1));
         else
             w[r] = wg[o];
     }
@@ -325,7 +330,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
                     if (COHERENT)
                         __builtin_amdgcn_raw_buffer_store_b32(
                             __builtin_bit_cast(unsigned, val), wrsrc,
-                            (unsigned)(((size_t)y * W + x) * sizeof(float)), 0, AUX_SC1);
+                            (unsigned)(((size_t)r * W + x) * sizeof(float)), 0, AUX_SC1);
                     else
                         wg[(size_t)y * W + x] = val;
                 }
@@ -857,8 +862,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (max_rounds <= 0) max_rounds = 1 << 16;
     const int K = 8;   // rounds enqueued between convergence checks
     max_rounds = (max_rounds + K - 1) / K * K;
+    // (64 rows of a window must be addressable with 32-bit byte offsets)
     const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr &&
-                           (size_t)H * W * sizeof(float) < (size_t)0xffffffffu;
+                           (size_t)64 * W * sizeof(float) < (size_t)0xffffffffu;
     const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
 
     // a worklist can only be resumed for the problem it was built for; when it cannot,
