@@ -144,14 +144,18 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     ctx.profile(True)
     ctx.profile_reset()
 
+    l_fixed = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
+    l_mask = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
+
     def lagoons():
-        for r in B.lagoons_detection_dev(hd_):
-            r.free()
+        ctx.check(ctx.lib.hdem_lagoons_detection_f32_dev(ctx.handle, hd_.ptr, S, S, l_fixed.ptr,
+                                                         scratch.ptr, l_mask.ptr))
     res["lagoons_detection"] = timed(lagoons)
     res["lagoons_detection"]["majority_ms"] = ctx.profile_get(B.K_MAJORITY)["ms"] / n_calls
     res["lagoons_detection"]["other_kernels_ms"] = ctx.profile_get(B.K_LAGOON)["ms"] / n_calls
     ctx.profile(False)
-    hd_.free()
+    for r in (hd_, l_fixed, l_mask):
+        r.free()
     return res
 
 
@@ -235,6 +239,8 @@ def main():
     elapsed = reduce_max(time.perf_counter() - t0)
 
     kt = ctx.profile_get(B.K_FILL_TILE)
+    kc = ctx.profile_get(B.K_FILL_COARSE)
+    kb = ctx.profile_get(B.K_BLOCKMAX)
     kr = ctx.profile_get(B.K_FILL_ROUND)
     ki = ctx.profile_get(B.K_FILL_INIT)
     k8 = ctx.profile_get(B.K_D8)
@@ -266,10 +272,10 @@ def main():
                        "visits_unchanged": info.get("visits_unchanged"),
                        "certifying_rounds": info.get("rounds"),
                        "halo_exchanges": info.get("exchanges", 0)},
-            "roofline": {"bound": "hbm", "kernel": "fill_async_kernel",
+            "roofline": {"bound": "hbm", "kernel": "fill_async_kernel<false, 0>",
                          "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fill_gbs / HBM_PEAK_GBS,
-                         "traffic": profiled_traffic("fill_async_kernel")
+                         "traffic": profiled_traffic("fill_async_kernel<false, 0>")
                          if (N == 1 and S == 16384) else None,
                          "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.csv: separate "
                                            "rocprofv3 --pmc passes of this command, bytes per launch, "
@@ -286,7 +292,13 @@ def main():
                             "achieved": FILL_BYTES_PER_CELL * kr["units"] / max(kr["ms"], 1e-9) / 1e6,
                             "unit": "GB/s", "launches": kr["launches"], "ms_total": kr["ms"],
                             "note": "certifying pass: 1 launch with work + 7 empty per step"},
-                        "fill_init_kernel": {"avg_launch_ms": ki["ms"] / max(ki["launches"], 1)}},
+                        "fill_init_kernel": {"avg_launch_ms": ki["ms"] / max(ki["launches"], 1)},
+                        "coarse_pre_solve": {
+                            "blockmax_avg_launch_ms": kb["ms"] / max(kb["launches"], 1),
+                            "fill_async_kernel<false, 1>_avg_launch_ms":
+                                kc["ms"] / max(kc["launches"], 1),
+                            "note": "fill of the 16x16 block maxima (1/256 of the cells): start "
+                                    "values of the fine solve; latency-bound"}},
         }
         if N == 1:
             out["filters"] = filter_paths(B, ctx, zd, wd, S)

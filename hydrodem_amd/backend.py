@@ -27,11 +27,11 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 # kernel ids for the timing query
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
 K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
-K_LAGOON, K_MAJORITY = 14, 15
+K_LAGOON, K_MAJORITY, K_FILL_COARSE = 14, 15, 16
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
-FILL_RESUME, FILL_GHOST_GIVEN = 0x100, 0x200
+FILL_RESUME, FILL_GHOST_GIVEN, FILL_NO_COARSE = 0x100, 0x200, 0x400
 
 
 class KernelStat(ctypes.Structure):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "hdem_set_stream": [_vp, _vp],
     "hdem_synchronize": [_vp],
     "hdem_set_fill_slice_us": [_vp, _i],
+    "hdem_set_fill_coarse_start": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_malloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
     "hdem_free": [_vp, _vp],
     "hdem_memcpy_h2d": [_vp, _vp, _vp, _c.c_size_t],
@@ -207,6 +208,12 @@ class Context:
     def set_fill_slice_us(self, microseconds):
         """Time slice of the asynchronous sink-fill phase (0 = to convergence)."""
         self.check(self.lib.hdem_set_fill_slice_us(self.handle, int(microseconds)))
+
+    def set_fill_coarse_start(self, coarse_ptr, ch, cw, block, row_map_ptr=None):
+        """Device pointers; see ``hdem_set_fill_coarse_start``."""
+        self.check(self.lib.hdem_set_fill_coarse_start(
+            self.handle, ctypes.c_void_p(coarse_ptr or 0), int(ch), int(cw), int(block),
+            ctypes.c_void_p(row_map_ptr or 0)))
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.hdem_set_stream(self.handle,

@@ -72,10 +72,31 @@ extern "C" int hdem_shutdown(hdem_ctx *ctx)
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     hdem_fourier_release(ctx);
     if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
+    if (ctx->coarse_buf) (void)hipFree(ctx->coarse_buf);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return HDEM_OK;
+}
+
+void *hdem_arena(hdem_ctx *ctx, size_t bytes)
+{
+    if (ctx->arena_bytes >= bytes) return ctx->arena;
+    if (ctx->arena) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+    }
+    const hipError_t e = hipMalloc(&ctx->arena, bytes);
+    if (e != hipSuccess) {
+        ctx->arena = nullptr;
+        hdem_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->arena_bytes = bytes;
+    return ctx->arena;
 }
 
 extern "C" int hdem_set_stream(hdem_ctx *ctx, void *hip_stream)

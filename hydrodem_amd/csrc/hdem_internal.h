@@ -56,6 +56,16 @@ struct hdem_ctx {
     const void *fill_last_z = nullptr, *fill_last_out = nullptr;
     bool fill_resumable = false;       // state words hold a consistent asynchronous worklist
     bool fill_quiescent = false;       // ... and the last call left nothing to do
+    // coarse start of the sink fill: a caller's filled coarse raster for the next INIT call
+    // (hdem_set_fill_coarse_start), and the buffer of the library's own coarse pre-solve
+    const float *start_coarse = nullptr;
+    const int32_t *start_row_map = nullptr;
+    int start_cw = 0, start_shift = 0;
+    void *coarse_buf = nullptr;
+    bool in_coarse_presolve = false;   // the fill in progress is that pre-solve
+    size_t coarse_bytes = 0;
+    void *arena = nullptr;             // scratch of the multi-kernel chains, grown on demand
+    size_t arena_bytes = 0;
     hdem_fourier_state *fourier = nullptr;
     int32_t *host_counts = nullptr;    // pinned: convergence counters
     size_t host_counts_len = 0;
@@ -72,6 +82,9 @@ struct hdem_scoped_timer {
 
 int hdem_fold_profile(hdem_ctx *ctx);   // sync + accumulate pending events
 void hdem_fourier_release(hdem_ctx *ctx);
+// A device buffer of at least `bytes` that stays with the context (one user at a time:
+// the chains carve it up themselves).  nullptr + error set on failure.
+void *hdem_arena(hdem_ctx *ctx, size_t bytes);
 
 static inline int hdem_check_raster(const void *in, const void *out, int H,
                                     int W)

@@ -390,7 +390,40 @@ extern "C" int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H
 }
 
 // TidyingLagoons.apply (:564-610): erode (img != 0) twice, expand 7, multiply with img,
-// 7 x 7 grey dilation.  scratch: 2 byte rasters + 1 float raster, taken from the device.
+// 7 x 7 grey dilation.  scratch: 2 byte rasters + 1 float raster (6 bytes per cell).
+static size_t round16(size_t n) { return (n + 15) / 16 * 16; }
+
+static int tidying(hdem_ctx *ctx, const float *img, int H, int W, float *out, char *scratch)
+{
+    const size_t n = (size_t)H * W;
+    uint8_t *a = (uint8_t *)scratch, *b = a + round16(n);
+    float *f = (float *)(b + round16(n));
+    morph_struct st;
+    if (int rc = make_struct(CROSS, 3, 3, &st)) return rc;
+    hipStream_t s = ctx->stream;
+    const unsigned blocks = (unsigned)((n + 4 * NT - 1) / (4 * NT));
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n);
+        hipLaunchKernelGGL(nonzero_kernel, dim3(blocks), dim3(NT), 0, s, img, n, a);
+    }
+    // a -> b -> a : two erosions, the result back in a
+    if (int rc = erode_n(ctx, a, H, W, st, 1, nullptr, b)) return rc;
+    if (int rc = erode_n(ctx, b, H, W, st, 1, nullptr, a)) return rc;
+    if (int rc = hdem_expand_u8_dev(ctx, a, H, W, 7, b)) return rc;
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n * 2);
+        hipLaunchKernelGGL(mask_product_kernel, dim3(blocks), dim3(NT), 0, s, img,
+                           (const uint8_t *)b, n, f);
+        hipLaunchKernelGGL(grey_dilation_kernel, dim3((W + GTX - 1) / GTX, (H + GTY - 1) / GTY),
+                           dim3(NT), (GTX + 6) * (GTY + 6) * sizeof(float), s, (const float *)f, H,
+                           W, 7, 7, out);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+static size_t tidying_scratch(size_t n) { return 2 * round16(n) + round16(n * sizeof(float)); }
+
 extern "C" int hdem_tidying_lagoons_f32_dev(hdem_ctx *ctx, const float *img, int H, int W,
                                             float *out)
 {
@@ -399,34 +432,9 @@ extern "C" int hdem_tidying_lagoons_f32_dev(hdem_ctx *ctx, const float *img, int
     HDEM_REQUIRE(img != out, HDEM_ERR_BAD_ARG, "tidying cannot run in place");
     if (int rc = window_ok(7, H, W)) return rc;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t n = (size_t)H * W;
-    hdem_dbuf a, b, f;
-    if (int rc = a.alloc(n)) return rc;
-    if (int rc = b.alloc(n)) return rc;
-    if (int rc = f.alloc(n * sizeof(float))) return rc;
-    morph_struct st;
-    if (int rc = make_struct(CROSS, 3, 3, &st)) return rc;
-    hipStream_t s = ctx->stream;
-    const unsigned blocks = (unsigned)((n + 4 * NT - 1) / (4 * NT));
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n);
-        hipLaunchKernelGGL(nonzero_kernel, dim3(blocks), dim3(NT), 0, s, img, n, (uint8_t *)a.p);
-    }
-    // a -> b -> a : two erosions, the result back in a
-    if (int rc = erode_n(ctx, (const uint8_t *)a.p, H, W, st, 1, nullptr, (uint8_t *)b.p)) return rc;
-    if (int rc = erode_n(ctx, (const uint8_t *)b.p, H, W, st, 1, nullptr, (uint8_t *)a.p)) return rc;
-    if (int rc = hdem_expand_u8_dev(ctx, (const uint8_t *)a.p, H, W, 7, (uint8_t *)b.p)) return rc;
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n * 2);
-        hipLaunchKernelGGL(mask_product_kernel, dim3(blocks), dim3(NT), 0, s, img,
-                           (const uint8_t *)b.p, n, (float *)f.p);
-        hipLaunchKernelGGL(grey_dilation_kernel, dim3((W + GTX - 1) / GTX, (H + GTY - 1) / GTY),
-                           dim3(NT), (GTX + 6) * (GTY + 6) * sizeof(float), s, (const float *)f.p,
-                           H, W, 7, 7, out);
-    }
-    HDEM_HIP_CHECK(hipGetLastError());
-    HDEM_HIP_CHECK(hipStreamSynchronize(s));               // the scratch buffers die here
-    return HDEM_OK;
+    char *scratch = (char *)hdem_arena(ctx, tidying_scratch((size_t)H * W));
+    if (!scratch) return HDEM_ERR_OOM;
+    return tidying(ctx, img, H, W, out, scratch);
 }
 
 // LagoonsDetection.apply (:613-661): CorrectNANValues -> MajorityFilter(11) ->
@@ -439,20 +447,20 @@ extern "C" int hdem_lagoons_detection_f32_dev(hdem_ctx *ctx, const float *hsheds
     if (int rc = hdem_check_raster(hsheds, mask, H, W)) return rc;
     if (int rc = window_ok(11, H, W)) return rc;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t n = (size_t)H * W;
-    hdem_dbuf fx, mj, tv;
-    if (!fixed) { if (int rc = fx.alloc(n * sizeof(float))) return rc; fixed = (float *)fx.p; }
-    if (!values) { if (int rc = tv.alloc(n * sizeof(float))) return rc; values = (float *)tv.p; }
-    if (int rc = mj.alloc(n * sizeof(float))) return rc;
+    const size_t n = (size_t)H * W, fbytes = round16(n * sizeof(float));
+    char *scratch = (char *)hdem_arena(ctx, 3 * fbytes + tidying_scratch(n));
+    if (!scratch) return HDEM_ERR_OOM;
+    float *major = (float *)scratch;
+    if (!fixed) fixed = (float *)(scratch + fbytes);
+    if (!values) values = (float *)(scratch + 2 * fbytes);
     if (int rc = hdem_correct_nan_f32_dev(ctx, hsheds, H, W, fixed)) return rc;
-    if (int rc = hdem_majority_f32_dev(ctx, fixed, H, W, 11, (float *)mj.p)) return rc;
-    if (int rc = hdem_tidying_lagoons_f32_dev(ctx, (const float *)mj.p, H, W, values)) return rc;
+    if (int rc = hdem_majority_f32_dev(ctx, fixed, H, W, 11, major)) return rc;
+    if (int rc = tidying(ctx, major, H, W, values, scratch + 3 * fbytes)) return rc;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n);
         hipLaunchKernelGGL(positive_kernel, dim3((unsigned)((n + 4 * NT - 1) / (4 * NT))), dim3(NT), 0,
                            ctx->stream, (const float *)values, n, mask);
     }
     HDEM_HIP_CHECK(hipGetLastError());
-    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return HDEM_OK;
 }

@@ -58,6 +58,9 @@ constexpr int ITER_MAX = 8;        // 4-scan iterations before the tile re-queue
 constexpr int INIT_NT = 256;
 constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
 constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (agent scope)
+constexpr int COARSE_SHIFT = 4;    // own coarse start: 16 x 16 blocks ...
+constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on (below, the
+                                   // two extra launches cost what they save)
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
 constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
 #ifdef HDEM_VISIT_PROF
@@ -615,7 +618,9 @@ __device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int 
     }
 }
 
-template <bool HAS_EPS>
+// ROLE only names the launch (0: the raster itself, 1: the coarse pre-solve of a larger
+// raster) so that profilers list the two apart.
+template <bool HAS_EPS, int ROLE>
 __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restrict__ zg,
                                                           float *wg, int H, int W, float eps,
                                                           int tiles_x, int tiles_y, int ntiles,
@@ -684,12 +689,23 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
                                                       float *__restrict__ w, int H, int W,
                                                       int tiles_x, int *tile_key,
                                                       int ghost_top, int ghost_bottom,
-                                                      int ghost_given)
+                                                      int ghost_given,
+                                                      const float *__restrict__ coarse, int cw,
+                                                      int shift,
+                                                      const int *__restrict__ row_map)
 {
     const int quads = (W + 3) / 4;
     const size_t q = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
     if (q >= (size_t)H * quads) return;
     const int y = (int)(q / quads), x = (int)(q % quads) * 4;
+    // start value of the free cells: +inf, or the filled level of the cell's block in a
+    // coarse (block maximum) raster -- an upper bound of the fill (hdem_coarsen.hip); the
+    // 4 cells of a lane share a block (blocks are >= 4 wide, x is a multiple of 4)
+    float level = HDEM_INF;
+    if (coarse) {
+        level = coarse[(size_t)(row_map ? row_map[y] : (y >> shift)) * cw + (x >> shift)];
+        if (level >= 3.0e38f) level = HDEM_INF;            // a nodata wall stays a wall
+    }
     // rows y-1, y, y+1, columns x-1 .. x+4 (clamped: a clamped duplicate cannot add a NaN
     // that is not already in the neighbourhood)
     float v[3][6];
@@ -730,9 +746,9 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
                 atomicMin(&tile_key[ty * tiles_x + tx], float_key(o[k]));
             }
         } else if (ghost) {
-            o[k] = zc != zc ? zc : HDEM_INF;
+            o[k] = zc != zc ? zc : fmaxf(level, zc);
         } else {
-            o[k] = pin ? zc : HDEM_INF;
+            o[k] = pin ? zc : fmaxf(level, zc);
             if (pin && zc == zc && tiles_x > 0 && xx < W) {
                 // the tile whose interior is nearest (ring cells belong to no interior)
                 const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
@@ -866,6 +882,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr &&
                            (size_t)64 * W * sizeof(float) < (size_t)0xffffffffu;
     const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
+    const int async_id = ctx->in_coarse_presolve ? HDEM_K_FILL_COARSE : HDEM_K_FILL_TILE;
 
     // a worklist can only be resumed for the problem it was built for; when it cannot,
     // every tile is due again (correct, just slower)
@@ -874,6 +891,51 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                       ctx->fill_last_out == w;
     bool resume = want_resume && use_async && same && ctx->fill_resumable;
     if (want_resume) flags |= HDEM_FILL_NO_VERIFY;
+    // ---- coarse start (INIT, eps = 0): the caller's coarse fill, or our own -------------
+    const float *coarse = nullptr;
+    const int *row_map = nullptr;
+    int coarse_cw = 0, coarse_shift = 0;
+    if (!(flags & HDEM_FILL_WARM) && eps == 0.0f) {
+        if (ctx->start_coarse) {
+            coarse = ctx->start_coarse;
+            row_map = ctx->start_row_map;
+            coarse_cw = ctx->start_cw;
+            coarse_shift = ctx->start_shift;
+        } else if (use_async && !(flags & (HDEM_FILL_NO_COARSE | HDEM_FILL_GHOST_TOP |
+                                           HDEM_FILL_GHOST_BOTTOM)) &&
+                   (int64_t)H * W >= (getenv("HDEM_COARSE_MIN_CELLS")
+                                         ? atoll(getenv("HDEM_COARSE_MIN_CELLS"))
+                                         : (int64_t)COARSE_MIN_CELLS)) {
+            // fill the block-maximum raster first: 1/256 of the cells, and every level in
+            // it bounds the fine fill of its block from above
+            const int b = 1 << COARSE_SHIFT, ch = (H + b - 1) / b, cwid = (W + b - 1) / b;
+            const size_t need = (size_t)2 * ch * cwid * sizeof(float);
+            if (ctx->coarse_bytes < need) {
+                if (ctx->coarse_buf) {
+                    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    HDEM_HIP_CHECK(hipFree(ctx->coarse_buf));
+                    ctx->coarse_buf = nullptr;
+                    ctx->coarse_bytes = 0;
+                }
+                HDEM_HIP_CHECK(hipMalloc(&ctx->coarse_buf, need));
+                ctx->coarse_bytes = need;
+            }
+            float *cz = (float *)ctx->coarse_buf, *cfill = cz + (size_t)ch * cwid;
+            if (int rc = hdem_blockmax_f32_dev(ctx, z, H, W, b, cz)) return rc;
+            ctx->in_coarse_presolve = true;
+            const int rc = hdem_sinkfill_f32_dev(ctx, cz, ch, cwid, 0.0f, 0,
+                                                 HDEM_FILL_INIT | HDEM_FILL_NO_VERIFY |
+                                                     HDEM_FILL_NO_COARSE,
+                                                 cfill, nullptr);
+            ctx->in_coarse_presolve = false;
+            if (rc) return rc;
+            coarse = cfill;
+            coarse_cw = cwid;
+            coarse_shift = COARSE_SHIFT;
+        }
+    }
+    ctx->start_coarse = nullptr;                // a caller's coarse raster is used once
+    ctx->start_row_map = nullptr;
     fill_ws ws;
     if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * 8, &resume, &ws)) return rc;
     // not resumable: fine if the last call on this problem left nothing queued (then the ACT
@@ -888,7 +950,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     hipStream_t st = ctx->stream;
     const unsigned tile_blocks = (unsigned)std::max(1, (ws.ntiles + INIT_NT - 1) / INIT_NT);
     const bool warm = (flags & HDEM_FILL_WARM) != 0;
-    int mode = warm ? (flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM)) : -1;
+    // (from a coarse start every tile has something to lower: all of them are due)
+    int mode = warm ? (flags & (HDEM_FILL_ACT_TOP | HDEM_FILL_ACT_BOTTOM)) : (coarse ? 0 : -1);
     // resuming with no replaced ghost row: nothing to add to the worklist (mode 0 would
     // mean "all tiles")
     const bool seed_async = !(resume && mode == 0);
@@ -901,7 +964,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
                            dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
                            flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM,
-                           flags & HDEM_FILL_GHOST_GIVEN);
+                           flags & HDEM_FILL_GHOST_GIVEN, coarse, coarse_cw, coarse_shift,
+                           row_map);
     }
     int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
     const bool did_async = use_async && ws.ntiles > 0;
@@ -916,14 +980,18 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         // or the caller's time slice (soft: the launch just stops taking tiles)
         const long long budget = slice_us > 0 ? (long long)slice_us * 100ll
                                               : 20000000ll + (long long)ws.ntiles * 200ll;
-        hdem_scoped_timer tm(ctx, HDEM_K_FILL_TILE, 0);
+        hdem_scoped_timer tm(ctx, async_id, 0);
         if (eps != 0.0f)
-            hipLaunchKernelGGL(fill_async_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H, W,
-                               eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state, ws.prio,
-                               ws.pend, ws.error, ws.stats, budget, slice_us > 0);
-        else
-            hipLaunchKernelGGL(fill_async_kernel<false>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
+            hipLaunchKernelGGL((fill_async_kernel<true, 0>), dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
+        else if (ctx->in_coarse_presolve)
+            hipLaunchKernelGGL((fill_async_kernel<false, 1>), dim3(ws.G), dim3(NT), 0, st, z, w,
+                               H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
+        else
+            hipLaunchKernelGGL((fill_async_kernel<false, 0>), dim3(ws.G), dim3(NT), 0, st, z, w,
+                               H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
                                ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
     }
     HDEM_HIP_CHECK(hipGetLastError());
@@ -981,7 +1049,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     HDEM_HIP_CHECK(hipStreamSynchronize(st));
     unsigned long long tot[STAT_WORDS] = {};
     for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
-    ctx->stats[HDEM_K_FILL_TILE].units += (int64_t)(tot[0] - tot[6]) * FT * FT;
+    ctx->stats[async_id].units += (int64_t)(tot[0] - tot[6]) * FT * FT;
     ctx->stats[HDEM_K_FILL_ROUND].units += (int64_t)tot[6] * FT * FT;
     if (trace)
         fprintf(stderr, "sink fill: visits %llu iterations %llu unchanged %llu requeued %llu, "
@@ -1019,6 +1087,27 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // the round driver leaves round stamps in the state words: no worklist to resume
     ctx->fill_resumable = did_async && !verify;
     ctx->fill_quiescent = converged != 0;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_set_fill_coarse_start(hdem_ctx *ctx, const float *coarse_filled, int ch,
+                                          int cw, int block, const int32_t *row_map)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (!coarse_filled) {
+        ctx->start_coarse = nullptr;
+        ctx->start_row_map = nullptr;
+        return HDEM_OK;
+    }
+    HDEM_REQUIRE(ch > 0 && cw > 0 && block >= 4 && block <= 256 && (block & (block - 1)) == 0,
+                 HDEM_ERR_BAD_ARG, "coarse raster %d x %d with block %d is not usable", ch, cw,
+                 block);
+    int shift = 0;
+    while ((1 << shift) < block) ++shift;
+    ctx->start_coarse = coarse_filled;
+    ctx->start_row_map = row_map;
+    ctx->start_cw = cw;
+    ctx->start_shift = shift;
     return HDEM_OK;
 }
 

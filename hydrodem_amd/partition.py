@@ -26,17 +26,19 @@ at exit is a fixed point of the global operator, hence the same bits as the
 single-GPU result.  D8 needs the ghost rows of the filled surface, which the
 last exchange leaves in place.
 
-Start values of the ghost rows.  A rank that starts with its ghost rows at +inf
-first fills against two walls and redoes most of that when the neighbours' real
-rows arrive (measured: 2.3x the tile visits of an undivided raster).  So the
-ranks first solve the *whole* raster on a coarse grid: each takes block maxima
-of its owned rows (``COARSE_BLOCK`` x ``COARSE_BLOCK`` cells, NaN -> wall),
-all-gathers them (W*H/b^2 floats in total) and fills the stacked coarse raster
--- redundantly, it is tiny.  A fine path that stays inside a chain of adjacent
-blocks never exceeds the chain's maxima, so the coarse fill bounds the fine
-fill from above, which is all a start value has to satisfy; the ghost rows
-start at the coarse level of their block.  Only for epsilon = 0 (with a
-gradient the bound would need the path length).
+Start values.  A rank that starts with its ghost rows at +inf first fills
+against two walls and redoes most of that when the neighbours' real rows arrive
+(measured: 2.3x the tile visits of an undivided raster).  So the ranks first
+solve the *whole* raster on a coarse grid: each takes block maxima of its owned
+rows (``COARSE_BLOCK`` x ``COARSE_BLOCK`` cells, NaN -> wall), all-gathers them
+(W*H/b^2 floats in total) and fills the stacked coarse raster -- redundantly, it
+is tiny.  A fine path that stays inside a chain of adjacent blocks never exceeds
+the chain's maxima, so the coarse fill bounds the fine fill from above, which is
+all a start value has to satisfy; every free cell of the block -- ghost rows
+included -- starts at the coarse level of its block instead of +inf
+(``hdem_set_fill_coarse_start``; the single-GPU solver does the same with its own
+coarse raster).  Only for epsilon = 0 (with a gradient the bound would need the
+path length).
 
 The local solver is injected (``solver=``): the HIP backend on GPUs; the CPU
 tests pass a NumPy solver so that this exchange logic runs under ``gloo``.
@@ -69,7 +71,7 @@ def local_range(rank, world, total_rows):
 # more than they save (17.3 ms unsliced, 18.9 ms with 2.5 ms slices), so it is off.
 DEFAULT_SLICE_US = 0
 # Edge of the blocks of the coarse pre-solve (power of two, 4..256).
-COARSE_BLOCK = 32
+COARSE_BLOCK = 16
 
 
 class HipLocalSolver:
@@ -102,6 +104,12 @@ class HipLocalSolver:
         finally:
             self.ctx.set_fill_slice_us(0)
         return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"], st["pending"]
+
+    def set_coarse_start(self, filled, block, row_map):
+        """Start values of the next INIT ``fill``: device tensors, see
+        ``hdem_set_fill_coarse_start``."""
+        self.ctx.set_fill_coarse_start(filled.data_ptr(), filled.shape[0], filled.shape[1],
+                                       block, row_map.data_ptr())
 
     def d8(self, w, out):
         backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
@@ -186,16 +194,16 @@ def _all_gather(dist, torch, t, world, group):
     return [p.to(t.device) for p in parts] if stage else parts
 
 
-def coarse_ghost_guess(z_local, rank, world, solver, block=COARSE_BLOCK, group=None):
-    """Upper bounds of the filled surface on this rank's ghost rows, from a fill of
-    the whole raster coarsened to block maxima (see the module docstring).
-    Returns (top, bottom) 1-D tensors (None where there is no ghost row)."""
+def coarse_start(z_local, rank, world, solver, block=COARSE_BLOCK, group=None):
+    """Start values from a fill of the whole raster coarsened to block maxima (see the
+    module docstring).  Returns (filled, row_map): the filled stacked coarse raster
+    (every rank holds the same one) and, per row of ``z_local`` (ghost rows included),
+    the coarse row that bounds it -- what ``hdem_set_fill_coarse_start`` takes."""
     import torch
     import torch.distributed as dist
 
     top, bottom = rank > 0, rank < world - 1
     owned = z_local[owned_slice(rank, world)]
-    width = z_local.shape[1]
     mine = solver.blockmax(owned.contiguous(), block)
     # ranks own floor or ceil(H/world) rows: pad to a common shape for the all_gather
     counts = torch.tensor([mine.shape[0]], dtype=torch.int64)
@@ -212,15 +220,12 @@ def coarse_ghost_guess(z_local, rank, world, solver, block=COARSE_BLOCK, group=N
     parts = _all_gather(dist, torch, padded, world, group)
     coarse = torch.cat([p[:n] for p, n in zip(parts, rows)]).contiguous()
     filled = torch.empty_like(coarse)
-    solver.fill(coarse, filled, 0.0, backend.FILL_INIT)
+    solver.fill(coarse, filled, 0.0, backend.FILL_INIT | backend.FILL_NO_VERIFY)
     first = sum(rows[:rank])                       # my first coarse row in the stack
-
-    def expand(coarse_row):
-        return coarse_row.repeat_interleave(block)[:width].contiguous()
-
-    g_top = expand(filled[first - 1]) if top else None
-    g_bot = expand(filled[first + rows[rank]]) if bottom else None
-    return g_top, g_bot
+    own = first + torch.arange(owned.shape[0], dtype=torch.int32) // block
+    row_map = torch.cat(([torch.tensor([first - 1], dtype=torch.int32)] if top else []) + [own] +
+                        ([torch.tensor([first + rows[rank]], dtype=torch.int32)] if bottom else []))
+    return filled, row_map.to(torch.int32).to(z_local.device)
 
 
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
@@ -242,14 +247,12 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         flags |= backend.FILL_GHOST_BOTTOM
     flag_dev = None
     sliced = world > 1
+    keep = None
     if world > 1 and eps == 0.0 and coarse_block:
-        g_top, g_bot = coarse_ghost_guess(z_local, rank, world, solver, coarse_block, group)
-        if top:
-            w[0].copy_(g_top)
-        if bottom:
-            w[-1].copy_(g_bot)
-        flags |= backend.FILL_GHOST_GIVEN
+        keep = coarse_start(z_local, rank, world, solver, coarse_block, group)
+        solver.set_coarse_start(keep[0], coarse_block, keep[1])
     visits, _, pending = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY, sliced)
+    del keep                                       # (alive until the solve has consumed them)
     exchanges = verifications = 0
     while world > 1:
         any_busy, ch_top, ch_bot = _exchange_and_vote(dist, torch, w, top, bottom, rank,

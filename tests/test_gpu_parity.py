@@ -439,6 +439,44 @@ def test_given_ghost_rows_are_start_values_not_pins():
     assert np.array_equal(np.nan_to_num(got, nan=-1), np.nan_to_num(want, nan=-1))
 
 
+@pytest.mark.parametrize("shape,block,nodata", [((300, 421), 16, False), ((517, 640), 8, True),
+                                                ((1024, 1024), 32, True), ((130, 90), 4, False)])
+def test_coarse_start_gives_the_same_bits(shape, block, nodata):
+    """INIT from the filled block-maximum raster (hdem_set_fill_coarse_start) instead of
+    +inf: an upper bound is all the relaxation needs, the result is the same fixed point."""
+    z = oracle.synth_dem(*shape)
+    if nodata:
+        z[shape[0] // 3:shape[0] // 3 + 5, 40:70] = np.nan
+        z[5, 5] = np.nan
+        z[-40:-20, -60:-58] = np.nan                       # a wall: cells behind stay reachable
+    ctx = backend.context()
+    zd = backend.DeviceRaster.from_host(z)
+    coarse = backend.blockmax_dev(zd, block)
+    cfill, _ = backend.sinkfill_dev(coarse, flags=backend.FILL_INIT | backend.FILL_NO_COARSE)
+    ctx.set_fill_coarse_start(cfill.ptr, coarse.shape[0], coarse.shape[1], block)
+    wd, st = backend.sinkfill_dev(zd)
+    want = c_oracle.sinkfill_pflood(z)
+    assert np.array_equal(np.nan_to_num(wd.to_host(), nan=-1), np.nan_to_num(want, nan=-1))
+    # used once: the next call starts from +inf again and agrees
+    wd2, st2 = backend.sinkfill_dev(zd)
+    assert np.array_equal(np.nan_to_num(wd2.to_host(), nan=-1), np.nan_to_num(want, nan=-1))
+    assert st["tiles"] == st2["tiles"]
+
+
+def test_own_coarse_pre_solve_small_raster(monkeypatch):
+    """The library's own coarse pre-solve (normally from 6000^2 cells on), forced on."""
+    monkeypatch.setenv("HDEM_COARSE_MIN_CELLS", "1")
+    for shape in ((700, 900), (64, 33), (333, 1100)):
+        z = oracle.synth_dem(*shape)
+        z[shape[0] // 2, shape[1] // 2] = np.nan
+        want = c_oracle.sinkfill_pflood(z)
+        got = hd.SinkFill().apply(z)
+        assert np.array_equal(np.nan_to_num(got, nan=-1), np.nan_to_num(want, nan=-1))
+        plain = backend.sinkfill_dev(backend.DeviceRaster.from_host(z),
+                                     flags=backend.FILL_INIT | backend.FILL_NO_COARSE)[0].to_host()
+        assert np.array_equal(np.nan_to_num(plain, nan=-1), np.nan_to_num(want, nan=-1))
+
+
 def test_time_sliced_fill_resumes_to_the_same_bits():
     """INIT with a short time slice leaves tiles queued; RESUME continues the same
     worklist; the result and a final certifying pass agree with the oracle."""

@@ -173,6 +173,7 @@ def test_python_constants_match_the_header():
     assert defines["HDEM_FILL_NO_VERIFY"] == backend.FILL_NO_VERIFY
     assert defines["HDEM_FILL_RESUME"] == backend.FILL_RESUME
     assert defines["HDEM_FILL_GHOST_GIVEN"] == backend.FILL_GHOST_GIVEN
+    assert defines["HDEM_FILL_NO_COARSE"] == backend.FILL_NO_COARSE
     enums = dict(re.findall(r"\b(HDEM_(?:K|ERR)_[A-Z0-9_]+|HDEM_OK)\s*=\s*(\d+)", header))
     assert int(enums["HDEM_K_FILL_TILE"]) == backend.K_FILL_TILE
     assert int(enums["HDEM_K_FILL_ROUND"]) == backend.K_FILL_ROUND

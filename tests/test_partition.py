@@ -26,17 +26,33 @@ class NumpyLocalSolver:
 
     def __init__(self, slice_sweeps=3):
         self.slice_sweeps = slice_sweeps
+        self.start = None
+
+    def set_coarse_start(self, filled, block, row_map):
+        self.start = (filled.numpy(), block, row_map.numpy())
 
     def fill(self, z, w, eps, flags, sliced=False):
         zn, wn = z.numpy(), w.numpy()
         if not flags & backend.FILL_WARM:
             w0 = oracle.sinkfill_init(zn)
+            level = np.inf
+            if self.start is not None and eps == 0:
+                filled, block, row_map = self.start
+                level = np.repeat(filled[row_map], block, axis=1)[:, :zn.shape[1]]
+                level = np.where(level >= 3e38, np.inf, level)
+                free = np.isinf(w0)
+                w0[free] = np.maximum(level, zn)[free]
+                level = level[[0, -1]][:, 1:-1]
+            self.start = None
             given = bool(flags & backend.FILL_GHOST_GIVEN)
+            lv = level if np.ndim(level) else np.full((2, zn.shape[1] - 2), np.inf)
             if flags & backend.FILL_GHOST_TOP:
-                start = np.maximum(wn[0, 1:-1], zn[0, 1:-1]) if given else np.inf
+                start = np.maximum(wn[0, 1:-1], zn[0, 1:-1]) if given else \
+                    np.maximum(lv[0], zn[0, 1:-1])
                 w0[0, 1:-1] = np.where(np.isnan(zn[0, 1:-1]), zn[0, 1:-1], start)
             if flags & backend.FILL_GHOST_BOTTOM:
-                start = np.maximum(wn[-1, 1:-1], zn[-1, 1:-1]) if given else np.inf
+                start = np.maximum(wn[-1, 1:-1], zn[-1, 1:-1]) if given else \
+                    np.maximum(lv[1], zn[-1, 1:-1])
                 w0[-1, 1:-1] = np.where(np.isnan(zn[-1, 1:-1]), zn[-1, 1:-1], start)
             wn[:] = w0
         sweeps = 0

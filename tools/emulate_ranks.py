@@ -21,6 +21,8 @@ for r in range(N):
     blocks.append({"z": zt, "w": torch.empty_like(zt), "top": top, "bot": bot, "pending": 0,
                    "solver": P.HipLocalSolver(0, slice_us=SLICE, own_context=True)})
 def timed_fill(b, flags):
+    if not (flags & B.FILL_WARM) and COARSE:
+        b["solver"].set_coarse_start(filled, COARSE, b["row_map"])
     torch.cuda.synchronize(); t = time.perf_counter()
     v, lowered, b["pending"] = b["solver"].fill(b["z"], b["w"], 0.0, flags, SLICE > 0)
     torch.cuda.synchronize(); return time.perf_counter() - t, v, lowered
@@ -41,10 +43,13 @@ if COARSE:
     first = 0
     for r, b in enumerate(blocks):
         n = parts[r].shape[0]
-        if b["top"]: b["w"][0].copy_(filled[first - 1].repeat_interleave(COARSE)[:W])
-        if b["bot"]: b["w"][-1].copy_(filled[first + n].repeat_interleave(COARSE)[:W])
+        owned = b["z"][P.owned_slice(r, N)].shape[0]
+        own = first + torch.arange(owned, dtype=torch.int32) // COARSE
+        rm = torch.cat(([torch.tensor([first - 1], dtype=torch.int32)] if b["top"] else []) + [own] +
+                       ([torch.tensor([first + n], dtype=torch.int32)] if b["bot"] else []))
+        b["row_map"] = rm.to(torch.int32).cuda()
         first += n
-    given = B.FILL_GHOST_GIVEN
+    given = 0
 ts = []
 for b in blocks:
     f = given | B.FILL_INIT | B.FILL_NO_VERIFY | (B.FILL_GHOST_TOP if b["top"] else 0) | (B.FILL_GHOST_BOTTOM if b["bot"] else 0)
