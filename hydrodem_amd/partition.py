@@ -78,15 +78,27 @@ class HipLocalSolver:
     """Local block solver on the HIP backend; tensors are CUDA torch tensors
     whose memory the kernels use in place (no copies)."""
 
-    def __init__(self, device_index=None, slice_us=DEFAULT_SLICE_US, own_context=False):
+    def __init__(self, device_index=None, slice_us=DEFAULT_SLICE_US, own_context=True):
         import torch
         self.torch = torch
         device_index = torch.cuda.current_device() if device_index is None else device_index
-        # the worklist of a time-sliced solve lives in the context: one context per block
-        # (own_context) when several blocks are solved in one process
+        # its own context by default: the stream below is bound to it, and the worklist of a
+        # time-sliced solve lives in it (one context per block solved in a process)
         self.ctx = backend.Context(device_index) if own_context else backend.context(device_index)
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # The kernels run on a torch stream of their own, ordered against torch's current
+        # stream with events on the way in and out of every call.  (Handing over torch's
+        # current stream directly does not work for the default stream: its handle is 0,
+        # the legacy NULL stream, which does not order against non-blocking streams.)
+        with torch.cuda.device(device_index):
+            self.stream = torch.cuda.Stream()
+        self.ctx.set_stream(self.stream.cuda_stream)
         self.slice_us = slice_us
+
+    def _enter(self):
+        self.stream.wait_stream(self.torch.cuda.current_stream())
+
+    def _exit(self):
+        self.torch.cuda.current_stream().wait_stream(self.stream)
 
     def _wrap(self, t, dtype):
         return backend.DeviceRaster.wrap(t.data_ptr(), tuple(t.shape), dtype,
@@ -98,11 +110,13 @@ class HipLocalSolver:
         honoured together with FILL_NO_VERIFY)."""
         sliced = bool(sliced and self.slice_us > 0)
         self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
+        self._enter()
         try:
             _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
                                          out=self._wrap(w, np.float32), flags=flags)
         finally:
             self.ctx.set_fill_slice_us(0)
+            self._exit()
         return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"], st["pending"]
 
     def set_coarse_start(self, filled, block, row_map):
@@ -112,27 +126,37 @@ class HipLocalSolver:
                                        block, row_map.data_ptr())
 
     def d8(self, w, out):
+        self._enter()
         backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
+        self._exit()
 
     def groves(self, img, mask, window_size, threshold, iterations):
         out = self.torch.empty_like(img)
+        scratch = self.torch.empty_like(img)
+        self._enter()
         backend.groves_dev(self._wrap(img, np.float32), self._wrap(mask, np.uint8),
                            window_size, threshold, iterations,
-                           out=self._wrap(out, np.float32))
+                           out=self._wrap(out, np.float32),
+                           scratch=self._wrap(scratch, np.float32))
+        self._exit()
         return out
 
     def boxmean(self, x, do_round):
         dt = np.float64 if x.dtype == self.torch.float64 else np.float32
         out = self.torch.empty_like(x)
+        self._enter()
         backend.boxmean3_dev(self._wrap(x, dt), do_round, out=self._wrap(out, dt))
+        self._exit()
         return out
 
     def blockmax(self, z, block):
         """Block maxima of ``z`` (contiguous rows), NaN -> FLT_MAX wall."""
         out = self.torch.empty((-(-z.shape[0] // block), -(-z.shape[1] // block)),
                                dtype=z.dtype, device=z.device)
+        self._enter()
         backend.blockmax_dev(self._wrap(z, np.float32), block,
                              out=self._wrap(out, np.float32))
+        self._exit()
         return out
 
 

@@ -397,7 +397,7 @@ def test_virtual_rank_partition_on_hip(world, H, W):
         torch.cuda.synchronize()
         codes.append(d[P.owned_slice(r, world)].cpu().numpy())
     assert np.array_equal(np.concatenate(codes), c_oracle.d8(want))
-    solver.ctx.set_stream(None)
+    solver.ctx.close()
 
 
 @pytest.mark.parametrize("shape,block", [((5, 7), 4), ((64, 256), 16), ((130, 1031), 32),
