@@ -131,8 +131,8 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     ctx.profile_reset()
     res["fourier_destripe"] = timed(lambda: B.fourier_destripe_dev(zd, out=scratch))
     n_calls = reps + 1
-    for name, kid in (("rocfft_c2c", B.K_FFT), ("rowsum", B.K_FOURIER_ROWSUM),
-                      ("detect", B.K_FOURIER_DETECT), ("mask", B.K_FOURIER_MASK),
+    for name, kid in (("rocfft_c2c", B.K_FFT), ("detect", B.K_FOURIER_DETECT),
+                      ("mask", B.K_FOURIER_MASK),
                       ("pointwise", B.K_FOURIER_POINT)):
         res["fourier_destripe"][name + "_ms"] = ctx.profile_get(kid)["ms"] / n_calls
     ctx.profile(False)

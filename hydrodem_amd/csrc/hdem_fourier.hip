@@ -15,10 +15,10 @@
 // maps them (shifted i <-> unshifted (i - n/2) mod n).  The full-raster mask is only
 // materialised when the caller asks for it.
 //
-// Kernels are HBM-bound stencils.  The hollow mean is separable: a row pass makes the
-// 55- and 5-wide row sums (float64: spectra span ten decades), a column pass slides
-// both down each column, compares, and rewrites the quadrant in place.  Algorithmic
-// bytes per quadrant cell and pass: row pass 4 + 16, column pass 16 + 4 + 4 + 1.
+// Kernels are HBM-bound stencils.  The hollow mean is separable and done in one pass per
+// detection: lanes slide float64 column sums (spectra span ten decades) down their
+// columns, a block-wide prefix turns them into the 55- and 5-wide window sums
+// (hollow_detect_kernel).  Algorithmic bytes per quadrant cell and pass: 4 + 4 + 1.
 #include <dlfcn.h>
 
 #include <cmath>
@@ -231,64 +231,93 @@ __global__ __launch_bounds__(NT) void quadrant_abs_kernel(const float2 *__restri
     q[(size_t)i * g.qw + j] = hypotf(v.x, v.y);
 }
 
-// Row pass of the hollow mean: sums over columns x-R..x+R and x-r..x+r of one row,
-// cells outside the array left out.  256 outputs per block from a 256 + 2R strip in LDS.
-template <int R, int r>
-__global__ __launch_bounds__(NT) void rowsum_kernel(const float *__restrict__ q, int h, int w,
-                                                    double *__restrict__ big,
-                                                    double *__restrict__ small)
-{
-    __shared__ float s[NT + 2 * R];
-    const int y = blockIdx.y, x0 = blockIdx.x * NT;
-    const float *row = q + (size_t)y * w;
-    for (int k = threadIdx.x; k < NT + 2 * R; k += NT) {
-        const int x = x0 - R + k;
-        s[k] = (x >= 0 && x < w) ? row[x] : 0.0f;
-    }
-    __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= w) return;
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int k = 0; k <= 2 * R; ++k) a += (double)s[threadIdx.x + k];
-#pragma unroll
-    for (int k = R - r; k <= R + r; ++k) b += (double)s[threadIdx.x + k];
-    big[(size_t)y * w + x] = a;
-    small[(size_t)y * w + x] = b;
-}
+// BlanksFourier.apply (:417-429) / DetectBlanksFourier (:457-461): q > factor x hollow mean.
+// (An earlier version made float64 row sums in one kernel and slid them down the columns
+// in a second: 45 B per cell and pass through HBM, 1.0 ms per pass at 8182^2.)
+// ONE pass over the quadrant, ~10 B per cell.  A block of 256 lanes owns 256 columns
+// (the 202 in the middle are its outputs, R on each side are context) and walks down
+// `seg` rows.  Each lane slides the two *column* sums of its column (float64; two
+// 4-byte row loads per step, the second a re-read from cache); per row the block turns
+// the 256 column sums into an inclusive prefix (wave scan by shuffles + the three wave
+// totals) and every output is P[c + R] - P[c - R - 1] -- two LDS reads instead of 55.
+// Out of place: q_out <- q * (1 - hit) (may be NULL: the second pass only needs the mask).
+constexpr int HT = 256;
 
-// Column pass + decision (BlanksFourier.apply :417-429): lane = column, each lane slides
-// the two window sums down SEG rows.  found: the mask of this pass; total: += found
-// (DetectBlanksFourier :457-461); q is rewritten as q * (1 - found).
 template <int R, int r>
-__global__ __launch_bounds__(64) void detect_kernel(const double *__restrict__ big,
-                                                    const double *__restrict__ small,
-                                                    float *q, int h, int w, float factor,
-                                                    int seg, uint8_t *found, uint8_t *total)
+__global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restrict__ q, int h, int w,
+                                                           float factor, int seg,
+                                                           float *__restrict__ q_out,
+                                                           uint8_t *found, uint8_t *total)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y0 = blockIdx.y * seg;
-    if (x >= w) return;
-    double sb = 0.0, ss = 0.0;
-    for (int y = max(y0 - R, 0); y <= min(y0 + R, h - 1); ++y) sb += big[(size_t)y * w + x];
-    for (int y = max(y0 - r, 0); y <= min(y0 + r, h - 1); ++y) ss += small[(size_t)y * w + x];
-    const int cols_b = min(x + R, w - 1) - max(x - R, 0) + 1;
-    const int cols_s = min(x + r, w - 1) - max(x - r, 0) + 1;
-    const int y1 = min(y0 + seg, h);
-    for (int y = y0; y < y1; ++y) {
-        const int rows_b = min(y + R, h - 1) - max(y - R, 0) + 1;
-        const int rows_s = min(y + r, h - 1) - max(y - r, 0) + 1;
-        const int cnt = rows_b * cols_b - rows_s * cols_s;
-        const size_t o = (size_t)y * w + x;
-        const float v = q[o];
-        // nanmean of an empty window is NaN and compares false
-        const bool hit = cnt > 0 && (double)v > (double)factor * ((sb - ss) / (double)cnt);
-        if (found) found[o] = hit ? 1 : 0;
-        if (total && hit) total[o] = (uint8_t)(total[o] + 1);
-        if (hit) q[o] = v * 0.0f;
-        if (y + R + 1 < h) sb += big[(size_t)(y + R + 1) * w + x];
-        if (y - R >= 0) sb -= big[(size_t)(y - R) * w + x];
-        if (y + r + 1 < h) ss += small[(size_t)(y + r + 1) * w + x];
-        if (y - r >= 0) ss -= small[(size_t)(y - r) * w + x];
+    __shared__ double pre[2][HT + 1];      // inclusive prefix of the big column sums (+ P[-1])
+    __shared__ double sml[2][HT];          // small column sums
+    __shared__ double wtot[2][HT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x * (HT - 2 * R) - R + tid;          // my column
+    const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, h);
+    const bool live = c >= 0 && c < w;
+    const float *col = q + (live ? c : 0);
+    double cb = 0.0, cs = 0.0;
+    if (live) {
+        for (int y = max(y0 - R, 0); y <= min(y0 + R, h - 1); ++y) cb += (double)col[(size_t)y * w];
+        for (int y = max(y0 - r, 0); y <= min(y0 + r, h - 1); ++y) cs += (double)col[(size_t)y * w];
+    }
+    const bool outputs = tid >= R && tid < HT - R && live;
+    const int cols_b = min(c + R, w - 1) - max(c - R, 0) + 1;
+    const int cols_s = min(c + r, w - 1) - max(c - r, 0) + 1;
+    if (tid == 0) pre[0][0] = pre[1][0] = 0.0;
+    // UN rows per trip: their loads (4 sliding-sum rows + the cell itself, per row) are all
+    // issued before the first scan, so the block-wide barriers of a row overlap the memory
+    // latency of the next ones instead of adding to it.
+    constexpr int UN = 4;
+    for (int yb = y0; yb < y1; yb += UN) {
+        float in_b[UN], out_b[UN], in_s[UN], out_s[UN], cell[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int y = yb + u;
+            in_b[u] = (live && y + R + 1 < h) ? col[(size_t)(y + R + 1) * w] : 0.0f;
+            out_b[u] = (live && y - R >= 0 && y < h) ? col[(size_t)(y - R) * w] : 0.0f;
+            in_s[u] = (live && y + r + 1 < h) ? col[(size_t)(y + r + 1) * w] : 0.0f;
+            out_s[u] = (live && y - r >= 0 && y < h) ? col[(size_t)(y - r) * w] : 0.0f;
+            cell[u] = (outputs && y < y1) ? col[(size_t)y * w] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int y = yb + u;
+            if (y >= y1) break;                                   // uniform over the block
+            const int buf = u & 1;
+            // inclusive scan of cb over the 256 lanes
+            double p = cb;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(p, o);
+                if (lane >= o) p += up;
+            }
+            if (lane == 63) wtot[buf][wave] = p;
+            sml[buf][tid] = cs;
+            __syncthreads();
+            for (int k = 0; k < wave; ++k) p += wtot[buf][k];
+            pre[buf][tid + 1] = p;
+            __syncthreads();
+            if (outputs) {
+                const double sb = pre[buf][tid + R + 1] - pre[buf][tid - R];
+                double ss = 0.0;
+#pragma unroll
+                for (int k = -r; k <= r; ++k) ss += sml[buf][tid + k];
+                const int rows_b = min(y + R, h - 1) - max(y - R, 0) + 1;
+                const int rows_s = min(y + r, h - 1) - max(y - r, 0) + 1;
+                const int cnt = rows_b * cols_b - rows_s * cols_s;
+                const size_t o = (size_t)y * w + c;
+                const float v = cell[u];
+                // nanmean of an empty window is NaN and compares false
+                const bool hit = cnt > 0 && (double)v > (double)factor * ((sb - ss) / (double)cnt);
+                if (found) found[o] = hit ? 1 : 0;
+                if (total && hit) total[o] = (uint8_t)(total[o] + 1);
+                if (q_out) q_out[o] = hit ? v * 0.0f : v;
+            }
+            cb += (double)in_b[u] - (double)out_b[u];
+            cs += (double)in_s[u] - (double)out_s[u];
+        }
     }
 }
 
@@ -376,24 +405,20 @@ int check_window(int window, int h, int w)
     return HDEM_OK;
 }
 
-// One BlanksFourier pass on a device quadrant (rewritten in place).
-int blanks_pass(hdem_ctx *ctx, float *q, int h, int w, double *big, double *small,
-                uint8_t *found, uint8_t *total)
+// One BlanksFourier pass on a device quadrant: q_out <- q with the peaks zeroed (NULL: not
+// needed), found / total as in detect_kernel.
+int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8_t *found,
+                uint8_t *total)
 {
-    hipStream_t st = ctx->stream;
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_ROWSUM, (int64_t)h * w);
-        hipLaunchKernelGGL((rowsum_kernel<27, 2>), grid2(w, h), dim3(NT), 0, st, q, h, w, big,
-                           small);
-    }
+    // rows one block walks: long runs amortise the 2R-row start-up of the sliding sums,
+    // short ones fill the chip on small quadrants (aim for >= 2048 blocks of 4 waves)
+    const int bx = (w + (HT - 54) - 1) / (HT - 54);
+    int seg = 256;
+    while (seg > 32 && (int64_t)bx * ((h + seg - 1) / seg) < 2048) seg /= 2;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_DETECT, (int64_t)h * w);
-        // rows one lane walks: long runs amortise the 2R-row start-up of the sliding sums,
-        // short ones fill the chip on small quadrants (aim for >= 8192 waves)
-        int seg = 256;
-        while (seg > 32 && (int64_t)((w + 63) / 64) * ((h + seg - 1) / seg) < 8192) seg /= 2;
-        hipLaunchKernelGGL((detect_kernel<27, 2>), dim3((w + 63) / 64, (h + seg - 1) / seg),
-                           dim3(64), 0, st, big, small, q, h, w, 4.0f, seg, found, total);
+        hipLaunchKernelGGL((hollow_detect_kernel<27, 2>), dim3(bx, (h + seg - 1) / seg), dim3(HT),
+                           0, ctx->stream, q, h, w, 4.0f, seg, q_out, found, total);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
@@ -410,12 +435,11 @@ extern "C" int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w
     if (int rc = hdem_check_raster(q, found, h, w)) return rc;
     if (int rc = check_window(55, h, w)) return rc;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
-    hdem_dbuf big, small;
-    if (int rc = big.alloc((size_t)h * w * sizeof(double))) return rc;
-    if (int rc = small.alloc((size_t)h * w * sizeof(double))) return rc;
-    if (int rc = blanks_pass(ctx, q, h, w, (double *)big.p, (double *)small.p, found, nullptr))
-        return rc;
-    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));     // big / small die with this scope
+    const size_t bytes = (size_t)h * w * sizeof(float);
+    float *tmp = (float *)hdem_arena(ctx, bytes);          // the pass is out of place
+    if (!tmp) return HDEM_ERR_OOM;
+    if (int rc = blanks_pass(ctx, q, h, w, tmp, found, nullptr)) return rc;
+    HDEM_HIP_CHECK(hipMemcpyAsync(q, tmp, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return HDEM_OK;
 }
 
@@ -480,17 +504,17 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
     if (int rc = ensure_plans(ctx, H, W)) return rc;
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)H * W, qn = (size_t)g.qh * g.qw;
-    // one allocation, carved up: spectrum | row sums (2 x float64) | quadrant | 4 byte masks |
-    // partial sums + mean
+    // one allocation, carved up: spectrum | quadrant and its copy without the first pass's
+    // peaks | 4 byte masks | partial sums + mean
     const size_t qn8 = (qn + 7) / 8 * 8;
-    const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(double) + qn8 * sizeof(float) +
-                         4 * qn8 + (SUM_BLOCKS + 1) * sizeof(double);
+    const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(float) + 4 * qn8 +
+                         (SUM_BLOCKS + 1) * sizeof(double);
     hdem_fourier_state *fs = ctx->fourier;
     if (!fs->scratch) HDEM_HIP_CHECK(hipMalloc(&fs->scratch, bytes));
     char *base = (char *)fs->scratch;
-    struct view { void *p; } F{base}, big{base + n * sizeof(float2)},
-        small{(char *)big.p + qn8 * sizeof(double)}, q{(char *)small.p + qn8 * sizeof(double)},
-        det{(char *)q.p + qn8 * sizeof(float)}, iso{(char *)det.p + qn8},
+    struct view { void *p; } F{base}, q{base + n * sizeof(float2)},
+        q1{(char *)q.p + qn8 * sizeof(float)}, det{(char *)q1.p + qn8 * sizeof(float)},
+        iso{(char *)det.p + qn8},
         exp{(char *)iso.p + qn8}, exp2{(char *)exp.p + qn8};
     double *partial = (double *)((char *)exp2.p + qn8), *mean = partial + SUM_BLOCKS;
     {
@@ -512,10 +536,12 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
                                (const float2 *)F.p, g, second, (float *)q.p);
         }
         HDEM_HIP_CHECK(hipMemsetAsync(det.p, 0, qn, st));
-        for (int pass = 0; pass < 2; ++pass)
-            if (int rc = blanks_pass(ctx, (float *)q.p, g.qh, g.qw, (double *)big.p,
-                                     (double *)small.p, nullptr, (uint8_t *)det.p))
-                return rc;
+        if (int rc = blanks_pass(ctx, (const float *)q.p, g.qh, g.qw, (float *)q1.p, nullptr,
+                                 (uint8_t *)det.p))
+            return rc;
+        if (int rc = blanks_pass(ctx, (const float *)q1.p, g.qh, g.qw, nullptr, nullptr,
+                                 (uint8_t *)det.p))
+            return rc;
         HDEM_HIP_CHECK(hipMemsetAsync(e, 0, qn, st));
         {
             hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_MASK, (int64_t)qn * 2);
