@@ -4,7 +4,8 @@
 // (FourierInitial, FourierProcessQuarters, DetectApplyFourier); FFT wrappers
 // extension_filters.py:348-480.
 //
-//   dem -> complex -> FFT (rocFFT, complex64 like scipy.fftpack on float32 input)
+//   dem - mean -> real-to-complex FFT (rocFFT single precision, like scipy.fftpack on float32
+//   input) into the left half of the spectrum, right half from the Hermitian symmetry
 //   -> |F| of the two upper quadrants in *shifted* coordinates, 10-cell margin
 //   -> 2 x { hollow 55x55 mean (inner 5x5 left out, cells past the quadrant edge left
 //            out), cells > 4 x mean are peaks and are zeroed for the next pass }
@@ -33,8 +34,10 @@ namespace {
 
 typedef struct rocfft_plan_t *rocfft_plan;
 typedef struct rocfft_execution_info_t *rocfft_execution_info;
-enum { ROCFFT_COMPLEX_FORWARD = 0, ROCFFT_COMPLEX_INVERSE = 1 };
-enum { ROCFFT_INPLACE = 0 };
+typedef struct rocfft_plan_description_t *rocfft_plan_description;
+enum { ROCFFT_COMPLEX_FORWARD = 0, ROCFFT_COMPLEX_INVERSE = 1, ROCFFT_REAL_FORWARD = 2 };
+enum { ROCFFT_INPLACE = 0, ROCFFT_NOTINPLACE = 1 };
+enum { ROCFFT_ARRAY_REAL = 2, ROCFFT_ARRAY_HERMITIAN_INTERLEAVED = 3 };
 enum { ROCFFT_SINGLE = 0 };
 
 struct rocfft_api {
@@ -49,6 +52,11 @@ struct rocfft_api {
     int (*info_destroy)(rocfft_execution_info) = nullptr;
     int (*info_set_work_buffer)(rocfft_execution_info, void *, size_t) = nullptr;
     int (*info_set_stream)(rocfft_execution_info, void *) = nullptr;
+    int (*desc_create)(rocfft_plan_description *) = nullptr;
+    int (*desc_destroy)(rocfft_plan_description) = nullptr;
+    int (*desc_set_data_layout)(rocfft_plan_description, int, int, const size_t *, const size_t *,
+                                size_t, const size_t *, size_t, size_t, const size_t *,
+                                size_t) = nullptr;
 };
 
 rocfft_api g_fft;
@@ -77,6 +85,9 @@ int load_rocfft()
     HDEM_SYM(info_destroy, "rocfft_execution_info_destroy");
     HDEM_SYM(info_set_work_buffer, "rocfft_execution_info_set_work_buffer");
     HDEM_SYM(info_set_stream, "rocfft_execution_info_set_stream");
+    HDEM_SYM(desc_create, "rocfft_plan_description_create");
+    HDEM_SYM(desc_destroy, "rocfft_plan_description_destroy");
+    HDEM_SYM(desc_set_data_layout, "rocfft_plan_description_set_data_layout");
 #undef HDEM_SYM
     HDEM_REQUIRE(g_fft.setup() == 0, HDEM_ERR_HIP, "rocfft_setup failed");
     g_fft.handle = h;
@@ -88,7 +99,7 @@ int load_rocfft()
 // per-context state: plans and the work buffer for one raster shape
 struct hdem_fourier_state {
     int H = 0, W = 0;
-    rocfft_plan fwd = nullptr, inv = nullptr;
+    rocfft_plan fwd = nullptr, inv = nullptr, r2c = nullptr;
     rocfft_execution_info info = nullptr;
     void *work = nullptr;
     size_t work_bytes = 0;
@@ -103,6 +114,7 @@ void hdem_fourier_release(hdem_ctx *ctx)
     if (!s) return;
     if (s->fwd) g_fft.plan_destroy(s->fwd);
     if (s->inv) g_fft.plan_destroy(s->inv);
+    if (s->r2c) g_fft.plan_destroy(s->r2c);
     if (s->info) g_fft.info_destroy(s->info);
     if (s->work) (void)hipFree(s->work);
     if (s->scratch) (void)hipFree(s->scratch);
@@ -126,10 +138,29 @@ int ensure_plans(hdem_ctx *ctx, int H, int W)
     HDEM_REQUIRE(g_fft.plan_create(&s->inv, ROCFFT_INPLACE, ROCFFT_COMPLEX_INVERSE, ROCFFT_SINGLE,
                                    2, lengths, 1, nullptr) == 0,
                  HDEM_ERR_HIP, "rocfft_plan_create (inverse %d x %d) failed", H, W);
-    size_t a = 0, b = 0;
+    // real -> Hermitian half, written straight into the left half of the full complex
+    // spectrum (row stride W): the destripe fills the right half from the symmetry
+    {
+        rocfft_plan_description d = nullptr;
+        HDEM_REQUIRE(g_fft.desc_create(&d) == 0, HDEM_ERR_HIP, "rocfft description_create failed");
+        const size_t strides[2] = {1, (size_t)W};
+        const int rc = g_fft.desc_set_data_layout(d, ROCFFT_ARRAY_REAL,
+                                                  ROCFFT_ARRAY_HERMITIAN_INTERLEAVED, nullptr,
+                                                  nullptr, 2, strides, (size_t)H * W, 2, strides,
+                                                  (size_t)H * W);
+        const int rc2 = rc ? rc
+                           : g_fft.plan_create(&s->r2c, ROCFFT_NOTINPLACE, ROCFFT_REAL_FORWARD,
+                                               ROCFFT_SINGLE, 2, lengths, 1, d);
+        g_fft.desc_destroy(d);
+        HDEM_REQUIRE(rc2 == 0, HDEM_ERR_HIP, "rocfft_plan_create (real forward %d x %d) failed",
+                     H, W);
+    }
+    size_t a = 0, b = 0, c3 = 0;
     g_fft.plan_get_work_buffer_size(s->fwd, &a);
     g_fft.plan_get_work_buffer_size(s->inv, &b);
+    g_fft.plan_get_work_buffer_size(s->r2c, &c3);
     s->work_bytes = a > b ? a : b;
+    if (c3 > s->work_bytes) s->work_bytes = c3;
     if (s->work_bytes) HDEM_HIP_CHECK(hipMalloc(&s->work, s->work_bytes));
     HDEM_REQUIRE(g_fft.info_create(&s->info) == 0, HDEM_ERR_HIP, "rocfft info_create failed");
     if (s->work_bytes)
@@ -149,6 +180,18 @@ int run_fft(hdem_ctx *ctx, bool inverse, float2 *data)
     hdem_scoped_timer tm(ctx, HDEM_K_FFT, (int64_t)s->H * s->W);
     HDEM_REQUIRE(g_fft.execute(inverse ? s->inv : s->fwd, in, nullptr, s->info) == 0,
                  HDEM_ERR_HIP, "rocfft_execute failed");
+    return HDEM_OK;
+}
+
+int run_r2c(hdem_ctx *ctx, float *real_in, float2 *spectrum)
+{
+    hdem_fourier_state *s = ctx->fourier;
+    HDEM_REQUIRE(g_fft.info_set_stream(s->info, ctx->stream) == 0, HDEM_ERR_HIP,
+                 "rocfft set_stream failed");
+    void *in[1] = {real_in}, *out[1] = {spectrum};
+    hdem_scoped_timer tm(ctx, HDEM_K_FFT, (int64_t)s->H * s->W);
+    HDEM_REQUIRE(g_fft.execute(s->r2c, in, out, s->info) == 0, HDEM_ERR_HIP,
+                 "rocfft_execute (real forward) failed");
     return HDEM_OK;
 }
 
@@ -212,13 +255,30 @@ __global__ __launch_bounds__(NT) void sum_final_kernel(const double *__restrict_
     if (threadIdx.x == 0) *mean = t / (double)n;
 }
 
-__global__ __launch_bounds__(NT) void to_complex_kernel(const float *__restrict__ x, size_t n,
-                                                        const double *__restrict__ mean,
-                                                        float2 *__restrict__ out)
+__global__ __launch_bounds__(NT) void to_real_kernel(const float *__restrict__ x, size_t n,
+                                                     const double *__restrict__ mean,
+                                                     float *__restrict__ out)
 {
-    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    const double m = mean ? *mean : 0.0;
-    if (i < n) out[i] = make_float2((float)((double)x[i] - m), 0.0f);
+    const size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4;
+    const double m = *mean;
+    if (i + 4 <= n) {
+        const hdem_f4 v = hdem_ld4u(x + i);
+        const hdem_f4 r = {(float)((double)v[0] - m), (float)((double)v[1] - m),
+                           (float)((double)v[2] - m), (float)((double)v[3] - m)};
+        hdem_st4u(out + i, r);
+    } else {
+        for (size_t k = i; k < n; ++k) out[k] = (float)((double)x[k] - m);
+    }
+}
+
+// The transform of a real raster is Hermitian: F[u][v] = conj(F[-u][-v]).  The real
+// forward transform fills columns 0 .. W/2 of every row; this fills the rest.
+__global__ __launch_bounds__(NT) void fill_right_half_kernel(float2 *F, int H, int W)
+{
+    const int first = W / 2 + 1, v = first + blockIdx.x * NT + threadIdx.x, u = blockIdx.y;
+    if (v >= W) return;
+    const float2 s = F[(size_t)(u ? H - u : 0) * W + (W - v)];
+    F[(size_t)u * W + v] = make_float2(s.x, -s.y);
 }
 
 // |F| of one upper quadrant (FourierInitial :857 + _get_firsts_quarters :953-966)
@@ -522,10 +582,16 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
         hipLaunchKernelGGL(sum_partial_kernel, dim3(SUM_BLOCKS), dim3(NT), 0, st, dem, n, partial);
         hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(NT), 0, st, (const double *)partial, n,
                            mean);
-        hipLaunchKernelGGL(to_complex_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st,
-                           dem, n, (const double *)mean, (float2 *)F.p);
+        // dem - mean goes through the caller's output raster, free until the last kernel
+        hipLaunchKernelGGL(to_real_kernel, dim3((unsigned)((n + 4 * NT - 1) / (4 * NT))), dim3(NT),
+                           0, st, dem, n, (const double *)mean, out);
     }
-    if (int rc = run_fft(ctx, false, (float2 *)F.p)) return rc;
+    if (int rc = run_r2c(ctx, out, (float2 *)F.p)) return rc;
+    if (W > 2) {
+        hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)n);
+        hipLaunchKernelGGL(fill_right_half_kernel, grid2(W - W / 2 - 1, H), dim3(NT), 0, st,
+                           (float2 *)F.p, H, W);
+    }
     if (mask) HDEM_HIP_CHECK(hipMemsetAsync(mask, 0, n, st));
     // both quadrants are detected on the untouched spectrum, then both are applied
     for (int second = 0; second < 2; ++second) {
