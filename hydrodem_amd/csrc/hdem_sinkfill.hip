@@ -57,6 +57,7 @@ constexpr int NT = 64;             // one wave per workgroup
 constexpr int ITER_MAX = 8;        // 4-scan iterations before the tile re-queues
 constexpr int INIT_NT = 256;
 constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
+constexpr int SEED_KEYS = 1 << 20;     // queue keys below this: seeds (flood order)
 constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (agent scope)
 constexpr int COARSE_SHIFT = 4;    // own coarse start: 16 x 16 blocks ...
 constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on (below, the
@@ -598,7 +599,7 @@ __device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int 
     // queue order: first come, first served (key = time of the first wake, 100 MHz
     // ticks).  Flood order (key = lowest elevation offered) was tried and is worse: a
     // tile woken early and low runs before its other neighbours have spoken.
-    const int now_key = (int)(wall_clock64() & 0x3fffffff);
+    const int now_key = SEED_KEYS + (int)(wall_clock64() & 0x3fffffff);
     // A tile that wakes nobody needs no release: nobody depends on seeing it before
     // the launch ends (its edge cannot lower any neighbour cell).
     if (changed && dirs) {
@@ -775,7 +776,10 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
 __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restrict__ tile_key,
                                                       int tiles_x, int tiles_y, int H, int mode,
                                                       int G, int S, int async, int *state,
-                                                      int *prio, int *pend, int stamp, int *any0)
+                                                      int *prio, int *pend, int stamp, int *any0,
+                                                      const float *__restrict__ coarse, int cw,
+                                                      int shift, const int *__restrict__ row_map,
+                                                      int W)
 {
     const int t = blockIdx.x * INIT_NT + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
@@ -797,7 +801,19 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
     if (async) {
         // (works on a fresh worklist and on one resumed from the previous slice)
         if (atomicCAS(&state[idx], ST_IDLE, ST_QUEUED) == ST_IDLE) {
-            prio[idx] = 0;                              // seeds go first (queue order: oldest)
+            // seeds go first (queue order: oldest).  From a coarse start every tile is a
+            // seed: they go in flood order, lowest coarse level first -- every workgroup
+            // walks its own tiles upwards, so the whole raster is swept roughly from the
+            // outlets up and a tile's first visit already finds its downstream neighbours
+            // lowered.  (Keys below SEED_KEYS; wake keys are clock ticks above it.)
+            int k = 0;
+            if (coarse && mode == 0) {
+                const int y = min(ty * FT + FT / 2, H - 1), x = min(tx * FT + FT / 2, W - 1);
+                const float level = coarse[(size_t)(row_map ? row_map[y] : (y >> shift)) * cw +
+                                           (x >> shift)];
+                k = min(max((float_key(level) >> 12) + (SEED_KEYS >> 1), 0), SEED_KEYS - 1);
+            }
+            prio[idx] = k;
             // 64 shards and one arrival per tile: ~1k arrivals per shard at 16384^2, once
             atomicAdd(pend + (owner % PEND_SHARDS) * PEND_STRIDE, 1);
         }
@@ -974,7 +990,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         if (seed_async)
             hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                                ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1,
-                               ws.state, ws.prio, ws.pend, 0, ws.any);
+                               ws.state, ws.prio, ws.pend, 0, ws.any, coarse, coarse_cw,
+                               coarse_shift, row_map, W);
         // wall-clock budget (100 MHz ticks): generous against the ~0.15 us per tile a
         // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second;
         // or the caller's time slice (soft: the launch just stops taking tiles)
@@ -1016,7 +1033,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (ws.ntiles > 0 && verify)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
-                           ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any);
+                           ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any, nullptr, 0,
+                           0, nullptr, W);
     while (ws.ntiles > 0 && verify && round < max_rounds && !converged) {
         for (int k = 0; k < K; ++k) {
             const int r = round + k;
