@@ -65,7 +65,7 @@ constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on 
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
 constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
 #ifdef HDEM_VISIT_PROF
-constexpr int STAT_WORDS = 13;
+constexpr int STAT_WORDS = 14;
 #else
 constexpr int STAT_WORDS = 7;      // per workgroup: visits, iterations, unchanged, re-queued,
                                    // busy ticks, idle ticks (100 MHz, async driver),
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
 #ifdef HDEM_VISIT_PROF
         if (threadIdx.x == 8) {
             for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 7 + k] += v.ticks[k];
-            stats[(size_t)b * STAT_WORDS + 12] += (unsigned long long)(now - t_v);   // + finish
+            stats[(size_t)b * STAT_WORDS + 13] += (unsigned long long)(now - t_v);   // finish
         }
 #endif
         busy += now - t_mark;
@@ -953,7 +953,11 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     ctx->start_coarse = nullptr;                // a caller's coarse raster is used once
     ctx->start_row_map = nullptr;
     fill_ws ws;
-    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * 8, &resume, &ws)) return rc;
+    // (HDEM_FILL_WGS_PER_CU: experiments; the machine holds 8 of these one-wave workgroups per CU)
+    const int wgs_per_cu = getenv("HDEM_FILL_WGS_PER_CU") ? atoi(getenv("HDEM_FILL_WGS_PER_CU")) : 8;
+    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * std::max(1, std::min(wgs_per_cu, 8)),
+                           &resume, &ws))
+        return rc;
     // not resumable: fine if the last call on this problem left nothing queued (then the ACT
     // flags describe all there is to do), otherwise every tile is due again
     if (want_resume && !resume && !(same && ctx->fill_quiescent))
@@ -1077,11 +1081,11 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
 #ifdef HDEM_VISIT_PROF
     if (trace && tot[0])
         fprintf(stderr, "  per-visit us (sync visits): load %.2f check %.2f zt %.2f iterate %.2f "
-                        "store %.2f wake-tests %.2f (changed visits %llu)\n",
+                        "store %.2f wake-tests %.2f finish (per visit) %.2f (changed visits %llu)\n",
                 tot[7] / 100.0 / tot[0], tot[8] / 100.0 / tot[0],
                 tot[9] / 100.0 / (tot[0] - tot[2] + 1), tot[10] / 100.0 / (tot[0] - tot[2] + 1),
                 tot[11] / 100.0 / (tot[0] - tot[2] + 1), tot[12] / 100.0 / (tot[0] - tot[2] + 1),
-                tot[0] - tot[2]);
+                tot[13] / 100.0 / tot[0], tot[0] - tot[2]);
 #endif
     if (stats) {
         stats->rounds = round;
