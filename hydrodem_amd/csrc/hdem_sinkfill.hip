@@ -1020,6 +1020,13 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // behind the asynchronous phase every tile is checked once (mode 0 = all tiles);
     // on its own it starts from the same seeds
     bool verify = !(did_async && (flags & HDEM_FILL_NO_VERIFY));
+    // The coarse pre-solve needs no host round trip at all: whatever state its launch ends
+    // in -- even one cut short -- is an upper bound of the coarse fill, which is all the
+    // fine solve asks of it; its counters are only read when somebody is looking.
+    if (ctx->in_coarse_presolve && did_async && !verify && !ctx->profiling && !trace && !stats) {
+        ctx->fill_resumable = ctx->fill_quiescent = false;
+        return HDEM_OK;
+    }
     if (!verify) {
         // trust the asynchronous phase unless it gave up; after a time slice, report how
         // many tiles are still queued (the worklist stays in the workspace for RESUME)
