@@ -605,6 +605,40 @@ def test_c_abi_error_codes():
             backend.sinkfill_dev(bd, max_rounds=2, flags=backend.FILL_SYNC_ONLY)[0].free()
 
 
+def test_c_abi_error_codes_of_the_newer_entry_points():
+    import ctypes
+    lib = backend.load_library()
+    ctx = backend.context()
+    msg = lambda: lib.hdem_last_error().decode()
+    z = backend.DeviceRaster.from_host(oracle.synth_dem(40, 48))
+    out = backend.DeviceRaster.empty((40, 48), np.float32)
+    m8 = backend.DeviceRaster.empty((40, 48), np.uint8)
+    h = ctx.handle
+    assert lib.hdem_blockmax_f32_dev(h, z.ptr, 40, 48, 24, out.ptr) == backend.BAD_ARG
+    assert "power of two" in msg()
+    assert lib.hdem_set_fill_coarse_start(h, z.ptr, 3, 3, 12, None) == backend.BAD_ARG
+    assert lib.hdem_set_fill_coarse_start(h, None, 0, 0, 0, None) == backend.OK      # clears
+    assert lib.hdem_set_fill_slice_us(h, -5) == backend.BAD_ARG
+    assert lib.hdem_majority_f32_dev(h, z.ptr, 40, 48, 17, out.ptr) == backend.BAD_ARG
+    assert lib.hdem_majority_f32_dev(h, z.ptr, 40, 48, 6, out.ptr) == backend.WINDOW_EVEN
+    assert lib.hdem_majority_f32_dev(h, z.ptr, 40, 48, 11, z.ptr) == backend.BAD_ARG
+    assert "in place" in msg()
+    st = (ctypes.c_uint8 * 4)(1, 1, 1, 1)
+    assert lib.hdem_binary_erosion_u8_dev(h, m8.ptr, 40, 48, st, 2, 2, 1, None, out.ptr) == backend.BAD_ARG
+    assert "odd-sized" in msg()
+    assert lib.hdem_binary_erosion_u8_dev(h, m8.ptr, 40, 48, None, 0, 0, 2, None, out.ptr) == backend.BAD_ARG
+    assert lib.hdem_grey_dilation_f32_dev(h, z.ptr, 40, 48, 4, 3, out.ptr) == backend.BAD_ARG
+    assert lib.hdem_fourier_destripe_f32_dev(h, z.ptr, 40, 48, out.ptr, None) == backend.WINDOW_HIGH
+    assert lib.hdem_blanks_fourier_f32_dev(h, z.ptr, 40, 48, m8.ptr) == backend.WINDOW_HIGH
+    assert lib.hdem_expand_u8_dev(h, m8.ptr, 40, 48, 13, m8.ptr) == backend.BAD_ARG
+    assert lib.hdem_memcpy_h2d_async(h, None, None, 16) == backend.BAD_ARG
+    p = ctypes.c_void_p()
+    assert lib.hdem_host_alloc(h, 1 << 20, ctypes.byref(p)) == backend.OK and p.value
+    assert lib.hdem_host_free(h, p) == backend.OK
+    for r in (z, out, m8):
+        r.free()
+
+
 def test_degenerate_rasters():
     for shape in [(1, 1), (1, 7), (7, 1), (2, 2), (2, 9), (3, 3)]:
         z = oracle.synth_dem(*shape)
