@@ -217,8 +217,10 @@ __host__ quad_geom make_geom(int H, int W)
 // shifted index -> index in the transform as rocFFT / fftpack lay it out
 __device__ __forceinline__ int unshift(int i, int n) { const int u = i - n / 2; return u < 0 ? u + n : u; }
 
-// Mean of the raster, deterministic (fixed tree): partial[b] per block, then one block.
-// The transform runs on dem - mean and the mean is added back before the final |.|:
+// A reference level of the raster: the mean of every step-th cell (about a million of
+// them; any level near the elevations serves), deterministic (fixed tree): partial[b] per
+// block, then one block.  The transform runs on dem - level and the level is added back
+// before the final |.|:
 // the same numbers as the reference's (only the zero frequency moves, which no quadrant
 // contains), at a tenth of the complex64 rounding error for elevations around 100 m.
 constexpr int SUM_BLOCKS = 1024;
@@ -235,11 +237,13 @@ __device__ __forceinline__ double block_sum(double v, double *s)
 }
 
 __global__ __launch_bounds__(NT) void sum_partial_kernel(const float *__restrict__ x, size_t n,
+                                                         size_t step,
                                                          double *__restrict__ partial)
 {
     __shared__ double s[NT];
     double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)SUM_BLOCKS * NT)
+    for (size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * step; i < n;
+         i += (size_t)SUM_BLOCKS * NT * step)
         acc += (double)x[i];
     const double t = block_sum(acc, s);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
@@ -579,9 +583,11 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
     double *partial = (double *)((char *)exp2.p + qn8), *mean = partial + SUM_BLOCKS;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)n);
-        hipLaunchKernelGGL(sum_partial_kernel, dim3(SUM_BLOCKS), dim3(NT), 0, st, dem, n, partial);
-        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(NT), 0, st, (const double *)partial, n,
-                           mean);
+        const size_t step = n >> 20 ? n >> 20 : 1;
+        hipLaunchKernelGGL(sum_partial_kernel, dim3(SUM_BLOCKS), dim3(NT), 0, st, dem, n, step,
+                           partial);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(NT), 0, st, (const double *)partial,
+                           (n + step - 1) / step, mean);
         // dem - mean goes through the caller's output raster, free until the last kernel
         hipLaunchKernelGGL(to_real_kernel, dim3((unsigned)((n + 4 * NT - 1) / (4 * NT))), dim3(NT),
                            0, st, dem, n, (const double *)mean, out);
