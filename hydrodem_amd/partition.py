@@ -253,7 +253,7 @@ def coarse_start(z_local, rank, world, solver, block=COARSE_BLOCK, group=None):
 
 
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
-                         max_exchanges=100000, group=None, coarse_block=COARSE_BLOCK):
+                         max_exchanges=100000, group=None, coarse_block=None):
     """Sink fill of a row-block partitioned raster.
 
     ``z_local``: torch tensor, local rows incl. ghost rows (see
@@ -271,6 +271,9 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         flags |= backend.FILL_GHOST_BOTTOM
     flag_dev = None
     sliced = world > 1
+    if coarse_block is None:
+        # every rank fills the whole stacked coarse raster: keep it to a few million cells
+        coarse_block = COARSE_BLOCK if world <= 4 else 2 * COARSE_BLOCK
     keep = None
     if world > 1 and eps == 0.0 and coarse_block:
         keep = coarse_start(z_local, rank, world, solver, coarse_block, group)
