@@ -272,8 +272,10 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     flag_dev = None
     sliced = world > 1
     if coarse_block is None:
-        # every rank fills the whole stacked coarse raster: keep it to a few million cells
-        coarse_block = COARSE_BLOCK if world <= 4 else 2 * COARSE_BLOCK
+        # (every rank fills the whole stacked coarse raster; at 8 x 16384^2 that is
+        # 8192 x 1024 cells and 1.6 ms, and 32 x 32 blocks would cost more in the fine
+        # solve than they save here: 16.1 against 15.4 ms predicted)
+        coarse_block = COARSE_BLOCK
     keep = None
     if world > 1 and eps == 0.0 and coarse_block:
         keep = coarse_start(z_local, rank, world, solver, coarse_block, group)
