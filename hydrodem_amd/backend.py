@@ -94,6 +94,8 @@ SIGNATURES = {
     "hdem_grey_dilation_f32_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
     "hdem_tidying_lagoons_f32_dev": [_vp, _vp, _i, _i, _vp],
     "hdem_lagoons_detection_f32_dev": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "hdem_sinkfill_d8_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp,
+                                 _c.POINTER(FillStats)],
     "hdem_boxmean3_f32": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f64": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
@@ -513,6 +515,20 @@ def lagoons_detection_dev(hsheds):
                                                  hsheds.shape[1], fixed.ptr, values.ptr,
                                                  mask.ptr), window=11, shape=hsheds.shape)
     return mask, fixed, values
+
+
+def sinkfill_d8_dev(z, eps=0.0, max_rounds=0, out=None, codes=None, flags=FILL_INIT):
+    """Sink fill + D8 of the filled surface (``hdem_sinkfill_d8_f32_dev``).
+    Returns (filled raster, D8 raster, stats)."""
+    _need(z, np.float32)
+    c = z.ctx
+    out = out or DeviceRaster.empty(z.shape, np.float32, c)
+    codes = codes or DeviceRaster.empty(z.shape, np.uint8, c)
+    st = FillStats()
+    c.check(c.lib.hdem_sinkfill_d8_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], float(eps),
+                                           int(max_rounds), int(flags), out.ptr, codes.ptr,
+                                           ctypes.byref(st)))
+    return out, codes, st.as_dict()
 
 
 def boxmean3_dev(x, do_round=True, out=None):

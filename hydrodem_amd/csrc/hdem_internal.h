@@ -63,6 +63,8 @@ struct hdem_ctx {
     int start_cw = 0, start_shift = 0;
     void *coarse_buf = nullptr;
     bool in_coarse_presolve = false;   // the fill in progress is that pre-solve
+    uint8_t *fill_d8 = nullptr;        // D8 raster the certifying pass of the next fill writes
+    bool fill_d8_done = false;         // ... and whether it did
     size_t coarse_bytes = 0;
     void *arena = nullptr;             // scratch of the multi-kernel chains, grown on demand
     size_t arena_bytes = 0;

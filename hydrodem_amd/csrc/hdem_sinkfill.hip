@@ -228,7 +228,7 @@ struct visit_result {
 template <bool HAS_EPS, bool COHERENT>
 __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
                                                    int H, int W, float eps, int ty, int tx,
-                                                   float *T)
+                                                   float *T, uint8_t *d8 = nullptr)
 {
     const int lane = threadIdx.x;
     const int y0 = ty * FT, x0 = tx * FT;              // window origin (= halo row/col)
@@ -400,6 +400,37 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         }
         PROF_MARK(5);
     }
+    // ---- D8 of a certified tile (round driver, on request) ------------------------------
+    // A visit that changes nothing has the final surface of the tile and of its halo in
+    // registers: the flow directions cost no second pass over W.  Same arithmetic and tie
+    // rule as d8_kernel (hdem_stencil.hip): drops (c - n) * w in float32, first maximum in
+    // the order NW, N, NE, W, E, SW, S, SE; a nodata centre has no direction.
+    if (!COHERENT && d8 && !out.changed) {
+        // (all 64 lanes take part: a lane shift reads nothing from a lane that is masked off)
+        const bool mine = lane >= 1 && lane <= FT && x <= W - 2;
+        const float dg = 0.70710678f;
+        float nw = lane_prev(w[0]), ne = lane_next(w[0]);
+        float cw = lane_prev(w[1]), ce = lane_next(w[1]);
+#pragma unroll
+        for (int r = 1; r <= FT; ++r) {
+            const float sw = lane_prev(w[r + 1]), se = lane_next(w[r + 1]);
+            const float c = w[r];
+            float best = 0.0f, d;
+            unsigned code = 0;
+            d = (c - nw) * dg;   if (d > best) { best = d; code = 32; }
+            d = (c - w[r - 1]);  if (d > best) { best = d; code = 64; }
+            d = (c - ne) * dg;   if (d > best) { best = d; code = 128; }
+            d = (c - cw);        if (d > best) { best = d; code = 16; }
+            d = (c - ce);        if (d > best) { best = d; code = 1; }
+            d = (c - sw) * dg;   if (d > best) { best = d; code = 8; }
+            d = (c - w[r + 1]);  if (d > best) { best = d; code = 4; }
+            d = (c - se) * dg;   if (d > best) { best = d; code = 2; }
+            if (z[r] == HDEM_INF) code = 0;
+            const int y = y0 + r;
+            if (mine && y <= H - 2) d8[(size_t)y * W + x] = (uint8_t)code;
+            nw = cw; ne = ce; cw = sw; ce = se;
+        }
+    }
     out.more = more;
     return out;
 }
@@ -435,7 +466,8 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
                                                           int tiles_x, int tiles_y, int ntiles,
                                                           int S, int *state, int stamp,
                                                           int *any_next,
-                                                          unsigned long long *stats)
+                                                          unsigned long long *stats,
+                                                          uint8_t *d8)
 {
     __shared__ float T[WN * TS];
     const int lane = threadIdx.x;
@@ -450,7 +482,11 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
             due &= due - 1;
             const int t = slot * G + b;
             const int ty = t / tiles_x, tx = t - ty * tiles_x;
-            const visit_result v = tile_visit<HAS_EPS, false>(zg, wg, H, W, eps, ty, tx, T);
+            visit_result v = tile_visit<HAS_EPS, false>(zg, wg, H, W, eps, ty, tx, T, d8);
+            // with flow directions asked for, a tile that still moved is seen again, and so
+            // are all its neighbours (their directions read its edge): every tile's last
+            // visit is one that changed nothing and wrote its codes from final values
+            if (d8 && v.changed) { v.dirs = 0xffu; v.more = true; }
             if (lane < 8 && ((v.dirs >> lane) & 1u)) {
                 const int t2 = neighbour_tile(lane, ty, tx, tiles_x, tiles_y);
                 if (t2 >= 0) {
@@ -898,6 +934,10 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     const bool use_async = !(flags & HDEM_FILL_SYNC_ONLY) && getenv("HDEM_FILL_SYNC") == nullptr &&
                            (size_t)64 * W * sizeof(float) < (size_t)0xffffffffu;
     const bool trace = getenv("HDEM_FILL_TRACE") != nullptr;
+    // (taken here: the coarse pre-solve below re-enters this function)
+    uint8_t *const d8_request = ctx->fill_d8;
+    ctx->fill_d8 = nullptr;
+    ctx->fill_d8_done = false;
     const int async_id = ctx->in_coarse_presolve ? HDEM_K_FILL_COARSE : HDEM_K_FILL_TILE;
 
     // a worklist can only be resumed for the problem it was built for; when it cannot,
@@ -1020,6 +1060,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // behind the asynchronous phase every tile is checked once (mode 0 = all tiles);
     // on its own it starts from the same seeds
     bool verify = !(did_async && (flags & HDEM_FILL_NO_VERIFY));
+    // flow directions on request (hdem_sinkfill_d8_f32_dev): written by the certifying
+    // pass when that pass sees every tile, i.e. behind the asynchronous phase
+    uint8_t *d8 = d8_request;
     // The coarse pre-solve needs no host round trip at all: whatever state its launch ends
     // in -- even one cut short -- is an upper bound of the coarse fill, which is all the
     // fine solve asks of it; its counters are only read when somebody is looking.
@@ -1041,33 +1084,37 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         if (async_error) { verify = true; pending = 0; }
         else converged = pending == 0;
     }
+    if (!(did_async && verify)) d8 = nullptr;
     if (ws.ntiles > 0 && verify)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
                            ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any, nullptr, 0,
                            0, nullptr, W);
+    // rounds per host check: behind the asynchronous phase the first round is expected to
+    // find nothing, so only one more is queued with it (an empty launch costs ~9 us)
+    const int KB = did_async ? 2 : K;
     while (ws.ntiles > 0 && verify && round < max_rounds && !converged) {
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < KB; ++k) {
             const int r = round + k;
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_ROUND, 0);
             if (eps != 0.0f)
                 hipLaunchKernelGGL(fill_round_kernel<true>, dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                    W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats);
+                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats, d8);
             else
                 hipLaunchKernelGGL(fill_round_kernel<false>, dim3(ws.G), dim3(NT), 0, st, z, w,
                                    H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats);
+                                   ST_ROUND0 + r, ws.any + r + 1, ws.stats, d8);
         }
         HDEM_HIP_CHECK(hipGetLastError());
-        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.any + round, (K + 1) * sizeof(int),
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.any + round, (KB + 1) * sizeof(int),
                                       hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < KB; ++k) {
             if (ctx->host_counts[k] == 0) { converged = 1; break; }
             ++round;
         }
-        if (!converged && ctx->host_counts[K] == 0) converged = 1;
+        if (!converged && ctx->host_counts[KB] == 0) converged = 1;
     }
     // ---- statistics ----------------------------------------------------------------
     const size_t stat_words = (size_t)ws.G * STAT_WORDS;
@@ -1113,9 +1160,36 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         hdem_set_error("sink fill did not converge in %d rounds", max_rounds);
         return HDEM_ERR_NOT_CONVERGED;
     }
+    ctx->fill_d8_done = d8 != nullptr && converged;
     // the round driver leaves round stamps in the state words: no worklist to resume
     ctx->fill_resumable = did_async && !verify;
     ctx->fill_quiescent = converged != 0;
+    return HDEM_OK;
+}
+
+// rows 0 and H-1, columns 0 and W-1 of a D8 raster: no direction on the raster ring
+__global__ __launch_bounds__(INIT_NT) void d8_ring_kernel(uint8_t *d8, int H, int W)
+{
+    const int i = blockIdx.x * INIT_NT + threadIdx.x;
+    if (i < W) { d8[i] = 0; d8[(size_t)(H - 1) * W + i] = 0; }
+    if (i < H) { d8[(size_t)i * W] = 0; d8[(size_t)i * W + W - 1] = 0; }
+}
+
+extern "C" int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float eps,
+                                        int max_rounds, int flags, float *w, uint8_t *d8,
+                                        hdem_fill_stats *stats)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(z, d8, H, W)) return rc;
+    ctx->fill_d8 = d8;
+    const int rc = hdem_sinkfill_f32_dev(ctx, z, H, W, eps, max_rounds, flags, w, stats);
+    ctx->fill_d8 = nullptr;
+    if (rc) return rc;
+    if (!ctx->fill_d8_done)              // no certifying pass over every tile: the plain kernel
+        return hdem_d8_f32_dev(ctx, w, H, W, d8);
+    hipLaunchKernelGGL(d8_ring_kernel, dim3((std::max(H, W) + INIT_NT - 1) / INIT_NT),
+                       dim3(INIT_NT), 0, ctx->stream, d8, H, W);
+    HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }
 

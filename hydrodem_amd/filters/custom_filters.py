@@ -241,12 +241,14 @@ class HydroConditioning(ComposedFilter):  # pylint: disable=too-few-public-metho
 
     def apply(self, image_to_filter):
         Filter.apply(self, image_to_filter)
+        fill = self.filters[0]
         with backend.DeviceRaster.from_host(image_to_filter, dtype=np.float32) as z:
-            with self.filters[0].apply_device(z) as filled:
-                with self.filters[1].apply_device(filled) as codes:
-                    filled.ctx.synchronize()
-                    self.filled = filled.to_host()
-                    return codes.to_host()
+            # one call: the certifying pass of the fill writes the flow directions
+            filled, codes, fill.stats = backend.sinkfill_d8_dev(
+                z, eps=fill.epsilon, max_rounds=fill.max_rounds)
+            with filled, codes:
+                self.filled = filled.to_host()
+                return codes.to_host()
 
 
 # ---------------------------------------------------------------------------

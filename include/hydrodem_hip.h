@@ -160,6 +160,14 @@ int hdem_sinkfill_f32(hdem_ctx *ctx, const float *z, int H, int W, float eps,
 int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W,
                           float eps, int max_rounds, int flags, float *w,
                           hdem_fill_stats *stats);
+/* Sink fill and D8 of the filled surface in one call (what HydroConditioning and the
+ * headline benchmark run).  The certifying pass of the fill holds every tile's final
+ * surface in registers; with this entry point it writes the flow directions from there
+ * instead of a second pass over w (same codes as hdem_d8_f32_dev, bit for bit; falls back
+ * to that kernel when the call has no certifying pass over every tile). */
+int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float eps,
+                             int max_rounds, int flags, float *w, uint8_t *d8,
+                             hdem_fill_stats *stats);
 /* Time slice of the asynchronous phase in microseconds (0 = run to convergence, the
  * default).  With a slice, an INIT/WARM call that has HDEM_FILL_NO_VERIFY returns
  * HDEM_OK with stats->pending > 0 when the slice ended first; continue with

@@ -25,11 +25,12 @@ def dem(built):
 
 def test_sinkfill_and_d8_full_size_bit_exact(dem):
     zd = backend.DeviceRaster.from_host(dem)
-    wd, st = backend.sinkfill_dev(zd)
+    wd, codes, st = backend.sinkfill_d8_dev(zd)               # the headline step
     assert st["converged"] and st["async_timed_out"] == 0
     w = wd.to_host()
     want = c_oracle.sinkfill_pflood(dem)
     assert np.array_equal(w, want)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
     assert (w >= dem).all() and np.array_equal(w[0], dem[0]) and np.array_equal(w[:, 0], dem[:, 0])
     # idempotent: filling the filled surface certifies without lowering anything
     _, st2 = backend.sinkfill_dev(wd, out=backend.DeviceRaster.empty(dem.shape, np.float32))

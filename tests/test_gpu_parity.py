@@ -171,6 +171,30 @@ def test_sinkfill_real_raster(golden):
     assert np.array_equal(hd.SinkFill().apply(z), c_oracle.sinkfill_pflood(z))
 
 
+@pytest.mark.parametrize("shape,variant,nodata", [((200, 333), "rough", False), ((519, 508), "srtm", False),
+                                                  ((700, 900), "rough", True), ((64, 33), "rough", False),
+                                                  ((3, 5), "rough", False), ((130, 1100), "srtm", True)])
+def test_fused_fill_and_d8_equal_the_two_kernels(shape, variant, nodata):
+    """hdem_sinkfill_d8_f32_dev: the certifying pass writes the D8 codes; same bits as the
+    fill followed by the stand-alone D8 kernel, and as the oracle."""
+    z = oracle.synth_dem(*shape, variant=variant)
+    if nodata:
+        z[shape[0] // 2:shape[0] // 2 + 4, 30:50] = np.nan
+        z[7, 7] = np.nan
+    zd = backend.DeviceRaster.from_host(z)
+    filled, codes, st = backend.sinkfill_d8_dev(zd)
+    want_w = c_oracle.sinkfill_pflood(z)
+    assert np.array_equal(np.nan_to_num(filled.to_host(), nan=-1), np.nan_to_num(want_w, nan=-1))
+    assert np.array_equal(codes.to_host(), backend.d8_dev(filled).to_host())
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want_w))
+    # also when the call has no certifying pass of its own (falls back to the D8 kernel)
+    _, codes2, _ = backend.sinkfill_d8_dev(zd, flags=backend.FILL_INIT | backend.FILL_NO_VERIFY)
+    assert np.array_equal(codes2.to_host(), codes.to_host())
+    _, codes3, _ = backend.sinkfill_d8_dev(zd, eps=1e-3)
+    w3 = c_oracle.sinkfill_pflood(z, eps=1e-3)
+    assert np.array_equal(codes3.to_host(), c_oracle.d8(w3))
+
+
 def test_hydroconditioning_chain():
     z = oracle.synth_dem(300, 400)
     chain = hd.HydroConditioning()

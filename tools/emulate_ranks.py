@@ -1,7 +1,7 @@
 """Emulate the N-rank row-block sink fill on ONE GPU, rank by rank, to predict the
 multi-GPU critical path: per phase (time slice or full local solve, then an exchange)
 the slowest rank counts, since ranks run in parallel on a real node.  Exploration only.
-usage: python tools/emulate_ranks.py N [rows_per_rank] [cols] [slice_us (0 = unsliced)] [coarse block (0 = +inf ghosts)]"""
+usage: python tools/emulate_ranks.py N [rows_per_rank] [cols] [slice_us (0 = unsliced)] [coarse block (0 = +inf ghosts)] [first_only (1: only the first solve is sliced)]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -13,6 +13,7 @@ N = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 SLICE = int(sys.argv[4]) if len(sys.argv) > 4 else P.DEFAULT_SLICE_US
 COARSE = int(sys.argv[5]) if len(sys.argv) > 5 else P.COARSE_BLOCK
+FIRST_ONLY = len(sys.argv) > 6 and sys.argv[6] == "1"
 H = N * S
 blocks = []
 for r in range(N):
@@ -24,7 +25,8 @@ def timed_fill(b, flags):
     if not (flags & B.FILL_WARM) and COARSE:
         b["solver"].set_coarse_start(filled, COARSE, b["row_map"])
     torch.cuda.synchronize(); t = time.perf_counter()
-    v, lowered, b["pending"] = b["solver"].fill(b["z"], b["w"], 0.0, flags, SLICE > 0)
+    sliced = SLICE > 0 and not (FIRST_ONLY and (flags & B.FILL_WARM))
+    v, lowered, b["pending"] = b["solver"].fill(b["z"], b["w"], 0.0, flags, sliced)
     torch.cuda.synchronize(); return time.perf_counter() - t, v, lowered
 crit = 0.0; rounds = []; visits = 0
 given = 0
