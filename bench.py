@@ -216,8 +216,8 @@ def main():
         info = {}
 
         def step():
-            _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt)
-            P.d8_distributed(wt, solver, out=dt_)
+            # (the last verifying pass of the fill writes the D8 codes of the block)
+            _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt, d8_out=dt_)
             info.update(st)
 
         def sync():

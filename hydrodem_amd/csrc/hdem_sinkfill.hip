@@ -1084,7 +1084,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         if (async_error) { verify = true; pending = 0; }
         else converged = pending == 0;
     }
-    if (!(did_async && verify)) d8 = nullptr;
+    // (the pass must see every tile: behind the asynchronous phase, or a WARM round-driver
+    // call with all tiles due -- the verifying call of the row-block loop)
+    if (!(verify && (did_async || (warm && mode == 0)))) d8 = nullptr;
     if (ws.ntiles > 0 && verify)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,

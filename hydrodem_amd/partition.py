@@ -104,16 +104,22 @@ class HipLocalSolver:
         return backend.DeviceRaster.wrap(t.data_ptr(), tuple(t.shape), dtype,
                                          ctx=self.ctx, keepalive=t)
 
-    def fill(self, z, w, eps, flags, sliced=False):
+    def fill(self, z, w, eps, flags, sliced=False, d8=None):
         """Returns (tile visits, whether any cell was lowered, tiles still queued).
         ``sliced``: stop after ``slice_us`` even if tiles are still queued (only
-        honoured together with FILL_NO_VERIFY)."""
+        honoured together with FILL_NO_VERIFY).  ``d8``: a uint8 tensor that receives
+        the flow directions of the filled block (the certifying pass writes them)."""
         sliced = bool(sliced and self.slice_us > 0)
         self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
         self._enter()
         try:
-            _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
-                                         out=self._wrap(w, np.float32), flags=flags)
+            if d8 is not None:
+                _, _, st = backend.sinkfill_d8_dev(self._wrap(z, np.float32), eps=eps,
+                                                   out=self._wrap(w, np.float32),
+                                                   codes=self._wrap(d8, np.uint8), flags=flags)
+            else:
+                _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
+                                             out=self._wrap(w, np.float32), flags=flags)
         finally:
             self.ctx.set_fill_slice_us(0)
             self._exit()
@@ -253,12 +259,15 @@ def coarse_start(z_local, rank, world, solver, block=COARSE_BLOCK, group=None):
 
 
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
-                         max_exchanges=100000, group=None, coarse_block=None):
+                         max_exchanges=100000, group=None, coarse_block=None, d8_out=None):
     """Sink fill of a row-block partitioned raster.
 
     ``z_local``: torch tensor, local rows incl. ghost rows (see
     :func:`local_range`), float32.  Returns (w_local, info): ``w_local`` has
-    the same shape, ghost rows holding the neighbours' final values."""
+    the same shape, ghost rows holding the neighbours' final values.  ``d8_out``
+    (uint8, same shape): also receives the D8 codes of the filled block, written by
+    the last verifying pass (rows of ghost rows are meaningless, as in
+    :func:`d8_distributed`)."""
     import torch
     import torch.distributed as dist
 
@@ -295,7 +304,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             # every rank is at rest: certify the whole block (round driver, all tiles
             # due); resume only if some rank still found something to lower
             v, lowered, pending = solver.fill(z_local, w, eps,
-                                              backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+                                              backend.FILL_WARM | backend.FILL_SYNC_ONLY,
+                                              d8=d8_out)
             visits += v
             verifications += 1
             again = torch.tensor([int(lowered)], dtype=torch.int32, device=flag_dev)
@@ -311,7 +321,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             v, _, pending = solver.fill(z_local, w, eps, act, sliced)
             visits += v
     if world == 1:
-        v, _, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+        v, _, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY,
+                              d8=d8_out)
         visits += v
     return w, {"tile_visits": int(visits), "exchanges": exchanges,
                "verifications": verifications}

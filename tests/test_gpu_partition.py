@@ -36,8 +36,11 @@ def _worker(rank, world, port, H, W, outdir):
         z = oracle.synth_dem(H, W, row0=g0, rows=g1 - g0)
         zt = torch.from_numpy(z).cuda()
         solver = P.HipLocalSolver(0)
-        w, info = P.sinkfill_distributed(zt, rank, world, solver)
-        d = P.d8_distributed(w, solver)
+        d = torch.empty(zt.shape, dtype=torch.uint8, device=zt.device)
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, d8_out=d)
+        torch.cuda.synchronize()
+        own_ = P.owned_slice(rank, world)
+        assert torch.equal(d[own_], P.d8_distributed(w, solver)[own_])
         torch.cuda.synchronize()
         own = P.owned_slice(rank, world)
         # the one-exchange stencils: groves x3 (21-row halo), box mean (1 row)

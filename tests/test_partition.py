@@ -31,7 +31,7 @@ class NumpyLocalSolver:
     def set_coarse_start(self, filled, block, row_map):
         self.start = (filled.numpy(), block, row_map.numpy())
 
-    def fill(self, z, w, eps, flags, sliced=False):
+    def fill(self, z, w, eps, flags, sliced=False, d8=None):
         zn, wn = z.numpy(), w.numpy()
         if not flags & backend.FILL_WARM:
             w0 = oracle.sinkfill_init(zn)
@@ -61,6 +61,8 @@ class NumpyLocalSolver:
             wn[:] = new
             sweeps += 1
             if changed == 0:
+                if d8 is not None:
+                    d8.numpy()[:] = oracle.d8_flow_direction(wn)
                 return sweeps, sweeps > 1, 0
             if sliced and flags & backend.FILL_NO_VERIFY and sweeps >= self.slice_sweeps:
                 return sweeps, True, 1
@@ -103,9 +105,11 @@ def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=
             z = full[g0:g1].copy()
         zt = torch.from_numpy(z)
         solver = NumpyLocalSolver()
+        d = torch.empty(zt.shape, dtype=torch.uint8)
         w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps,
-                                         coarse_block=coarse_block)
-        d = P.d8_distributed(w, solver)
+                                         coarse_block=coarse_block, d8_out=d)
+        assert torch.equal(d[P.owned_slice(rank, world)],
+                           P.d8_distributed(w, solver)[P.owned_slice(rank, world)])
         own = P.owned_slice(rank, world)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), w=w.numpy()[own], d=d.numpy()[own],
                  exchanges=info["exchanges"])
