@@ -127,9 +127,11 @@ struct scan_masks {                 // wave-uniform (SGPR) lane masks of changed
 // Lines 0 and 63 and lanes 0 and 63 are the pinned ring (z == w there, so med3
 // returns w).  Needs z[i] <= w[i], which every valid upper bound of W* satisfies.
 template <bool HAS_EPS>
-__device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN], float eps,
-                                           scan_masks &m)
+__device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN], float eps)
 {
+    // (no change detection in here: a compare per row step is a fifth of the scan's
+    // vector instructions, and the visit only needs to know which of its four edge lines
+    // moved -- it compares those around the scans instead)
     float pf = w[0], pb = w[WN - 1];
 #pragma unroll
     for (int k = 1; k <= WN - 2; ++k) {
@@ -138,15 +140,9 @@ __device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN],
         float cb = fminf(fminf(pb, lane_prev(pb)), lane_next(pb));
         if (HAS_EPS) { cf = cf + eps; cb = cb + eps; }
         const float nf = __builtin_amdgcn_fmed3f(z[i], w[i], cf);
-        if (i == 1) or_changed(m.first, nf, w[i]);
-        else if (i == WN - 2) or_changed(m.last, nf, w[i]);
-        else or_changed(m.all, nf, w[i]);
         w[i] = nf;
         pf = nf;
         const float nb = __builtin_amdgcn_fmed3f(z[j], w[j], cb);
-        if (j == 1) or_changed(m.first, nb, w[j]);
-        else if (j == WN - 2) or_changed(m.last, nb, w[j]);
-        else or_changed(m.all, nb, w[j]);
         w[j] = nb;
         pb = nb;
     }
@@ -285,23 +281,45 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
 #endif
     out.dirs = 0;
     out.iters = 0;
-    scan_masks V = {0, 0, 0}, Hm = {0, 0, 0};          // cumulative over the visit
+    scan_masks V = {0, 0, 0};
     check_rows<HAS_EPS>(z, w, eps, V);
     V.all |= V.first | V.last;
     bool more = V.all != 0;
     out.changed = more;
+    // lanes whose cell of row 1 / row 62 / column 1 / column 62 moved during the visit
+    // (columns: lane = row) -- what the wake tests below are gated on
+    const unsigned long long b1 = 1ull << 1, bl = 1ull << FT;
+    unsigned long long mv_r1 = V.first, mv_r62 = V.last, mv_c1 = V.all & b1, mv_c62 = V.all & bl;
     PROF_MARK(1);
     if (more) {
         float zt[WN];
 #pragma unroll
         for (int r = 0; r < WN; ++r) zt[r] = z[r];
         transpose(zt, T, lane);                        // zt: lane = row
+        // the four edge lines as they are now; the columns sit in lanes 1 and 62 and come
+        // back through LDS as lane = row vectors
+        float r1_prev = w[1], r62_prev = w[FT];
+        if (lane == 1 || lane == FT) {
+            float *dst = T + (lane == 1 ? 0 : WN);
+#pragma unroll
+            for (int r = 0; r < WN; ++r) dst[r] = w[r];
+        }
+        __syncthreads();
+        float c1_prev = T[lane], c62_prev = T[WN + lane];
+        __syncthreads();
         PROF_MARK(2);
         for (; out.iters < ITER_MAX && more; ++out.iters) {
-            scan_masks v = {0, 0, 0}, h = {0, 0, 0};
-            scan_lines<HAS_EPS>(z, w, eps, v);         // north -> south and south -> north
+            scan_lines<HAS_EPS>(z, w, eps);            // north -> south and south -> north
             transpose(w, T, lane);
-            scan_lines<HAS_EPS>(zt, w, eps, h);        // west -> east and east -> west
+            or_changed(mv_c1, w[1], c1_prev);          // columns: what the vertical scans (and
+            or_changed(mv_c62, w[FT], c62_prev);       // the last check) did to them
+            c1_prev = w[1];
+            c62_prev = w[FT];
+            scan_lines<HAS_EPS>(zt, w, eps);           // west -> east and east -> west
+            or_changed(mv_c1, w[1], c1_prev);
+            or_changed(mv_c62, w[FT], c62_prev);
+            c1_prev = w[1];
+            c62_prev = w[FT];
             // back to lane = column
 #pragma unroll
             for (int i = 0; i < WN; ++i) T[lane * TS + i] = w[i];
@@ -309,15 +327,17 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
 #pragma unroll
             for (int i = 0; i < WN; ++i) w[i] = T[i * TS + lane];
             __syncthreads();
+            or_changed(mv_r1, w[1], r1_prev);          // rows: both scans of this iteration
+            or_changed(mv_r62, w[FT], r62_prev);
             scan_masks c = {0, 0, 0};
             check_rows<HAS_EPS>(z, w, eps, c);         // convergence test (and one more T step)
             c.all |= c.first | c.last;
-            v.all |= v.first | v.last | c.all;         // `all` skips lines 1 and 62 in the scans
-            v.first |= c.first;
-            v.last |= c.last;
-            h.all |= h.first | h.last;
-            V.first |= v.first; V.last |= v.last; V.all |= v.all;
-            Hm.first |= h.first; Hm.last |= h.last; Hm.all |= h.all;
+            mv_r1 |= c.first;
+            mv_r62 |= c.last;
+            mv_c1 |= c.all & b1;
+            mv_c62 |= c.all & bl;
+            r1_prev = w[1];
+            r62_prev = w[FT];
             more = c.all != 0;
         }
 
@@ -350,7 +370,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         // w[n] is the halo value held since the load (stale means higher: the test
         // errs towards waking).  Rows first: lane c tests halo cell (0, c) / (63, c)
         // against my row 1 / 62 at lanes c-1, c, c+1.
-        const unsigned long long b1 = 1ull << 1, bl = 1ull << FT, mid = ((1ull << FT) - 1) << 1;
+        const unsigned long long mid = ((1ull << FT) - 1) << 1;
         const bool inner = lane >= 1 && lane <= FT;
         const float e1 = inner ? w[1] : HDEM_INF, e62 = inner ? w[FT] : HDEM_INF;
         // lanes 0/63 of the shifted copies read 0 under bound_ctrl: rebuild them as +inf
@@ -363,8 +383,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         unsigned long long north = 0, south = 0;
         or_less(north, cn, w[0]);
         or_less(south, cs, w[WN - 1]);
-        const bool row1_moved = V.first != 0 || (Hm.all & b1);
-        const bool row62_moved = V.last != 0 || (Hm.all & bl);
+        const bool row1_moved = mv_r1 != 0, row62_moved = mv_r62 != 0;
         if (row1_moved) {
             if (north & mid) out.dirs |= 1u << 1;                                  // N
             if (north & 1ull) out.dirs |= 1u << 0;                                 // NW
@@ -377,8 +396,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         }
         // Columns: lane 0 holds the west halo column, lane 1 my column 1 (lane 63 / 62
         // for the east); row r of the halo is tested against rows r-1, r, r+1.
-        const bool col1_moved = (V.all & b1) || Hm.first != 0;
-        const bool col62_moved = (V.all & bl) || Hm.last != 0;
+        const bool col1_moved = mv_c1 != 0, col62_moved = mv_c62 != 0;
         if (col1_moved || col62_moved) {
             unsigned long long side = 0;   // bit 0: west halo can drop, bit 63: east halo
             // q[r] = my edge column next to this lane's halo column (lane 0 <- lane 1,
