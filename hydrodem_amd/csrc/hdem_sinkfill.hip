@@ -258,17 +258,23 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         else
             w[r] = wg[o];
     }
+    // Normalise: nodata (NaN) becomes the wall +inf in both arrays (fminf returns the
+    // operand that is a number), cells outside the raster likewise, and the cells that
+    // are pinned for this visit -- window ring, raster ring -- get z = w so that the
+    // relaxation leaves them alone.  Every visit pays this, so it is kept to ~3 vector
+    // operations per row: what depends on the lane is decided once, what depends on the
+    // row is uniform.
+    const bool lane_pin = lane == 0 || lane == WN - 1 || x == 0 || x >= W - 1;
+    const bool lane_out = x >= W;
+    const bool partial = x0 + WN > W || y0 + WN > H;   // uniform: the window overhangs
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const int y = y0 + r;
-        const bool inside = x < W && y < H;
-        float zc = inside ? z[r] : HDEM_INF, wc = inside ? w[r] : HDEM_INF;
-        const bool nan = zc != zc;
-        if (wc != wc) wc = HDEM_INF;
-        // window ring, raster ring and everything outside: pinned for this visit
-        const bool pinned = r == 0 || r == WN - 1 || lane == 0 || lane == WN - 1 ||
-                            y == 0 || y >= H - 1 || x == 0 || x >= W - 1;
-        z[r] = nan ? HDEM_INF : (pinned ? wc : zc);
+        float wc = fminf(w[r], HDEM_INF), zc = fminf(z[r], HDEM_INF);
+        if (partial && (lane_out || y >= H)) { wc = HDEM_INF; zc = HDEM_INF; }
+        const bool row_pin = r == 0 || r == WN - 1 || y == 0 || y >= H - 1;   // uniform
+        // (a pinned nodata cell has w = NaN -> +inf as well, so z = w is the wall there too)
+        z[r] = (row_pin || lane_pin) ? wc : zc;
         w[r] = wc;
     }
 
