@@ -132,17 +132,43 @@ __device__ __forceinline__ void scan_lines(const float (&z)[WN], float (&w)[WN],
     // (no change detection in here: a compare per row step is a fifth of the scan's
     // vector instructions, and the visit only needs to know which of its four edge lines
     // moved -- it compares those around the scans instead)
+    // One step of both chains as one hand-scheduled block.  The lane shifts ride on the
+    // mins (v_min_f32_dpp; the intrinsic route is v_mov_dpp x2 + v_min3, and neither the
+    // DPP combiner nor the instruction selector folds wave shifts): 6 vector instructions
+    // per step pair instead of 8 plus hazard nops.  A DPP read needs two wait states
+    // after a vector write of its source; the two chains are interleaved so that there is
+    // always one full instruction of the other chain in between -- the compiler cannot
+    // see into the block, so the order below is the hazard management.  Lanes 0 / 63
+    // take the min with 0 (bound_ctrl): they are pinned ring lanes, z = w clamps them.
     float pf = w[0], pb = w[WN - 1];
+    // (whatever wrote w[0] / w[63] last, the first DPP read below is two wait states away)
+    asm volatile("s_nop 1" : "+v"(pf), "+v"(pb));
 #pragma unroll
     for (int k = 1; k <= WN - 2; ++k) {
         const int i = k, j = WN - 1 - k;
-        float cf = fminf(fminf(pf, lane_prev(pf)), lane_next(pf));
-        float cb = fminf(fminf(pb, lane_prev(pb)), lane_next(pb));
-        if (HAS_EPS) { cf = cf + eps; cb = cb + eps; }
-        const float nf = __builtin_amdgcn_fmed3f(z[i], w[i], cf);
+        float t1, t2, cf, cb, nf, nb;
+        if (HAS_EPS)
+            asm("v_min_f32_dpp %0, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %1, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %2, %6, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %3, %7, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_add_f32 %2, %2, %12\n\t"
+                "v_add_f32 %3, %3, %12\n\t"
+                "v_med3_f32 %4, %8, %9, %2\n\t"
+                "v_med3_f32 %5, %10, %11, %3"
+                : "=&v"(t1), "=&v"(t2), "=&v"(cf), "=&v"(cb), "=&v"(nf), "=&v"(nb)
+                : "v"(pf), "v"(pb), "v"(z[i]), "v"(w[i]), "v"(z[j]), "v"(w[j]), "v"(eps));
+        else
+            asm("v_min_f32_dpp %0, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %1, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %2, %6, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_min_f32_dpp %3, %7, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_med3_f32 %4, %8, %9, %2\n\t"
+                "v_med3_f32 %5, %10, %11, %3"
+                : "=&v"(t1), "=&v"(t2), "=&v"(cf), "=&v"(cb), "=&v"(nf), "=&v"(nb)
+                : "v"(pf), "v"(pb), "v"(z[i]), "v"(w[i]), "v"(z[j]), "v"(w[j]));
         w[i] = nf;
         pf = nf;
-        const float nb = __builtin_amdgcn_fmed3f(z[j], w[j], cb);
         w[j] = nb;
         pb = nb;
     }
