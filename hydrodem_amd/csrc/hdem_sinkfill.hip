@@ -339,10 +339,13 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         __syncthreads();
         float c1_prev = T[lane], c62_prev = T[WN + lane];
         __syncthreads();
+        float hl = HDEM_INF, hr = HDEM_INF;            // the halo columns as lane = row vectors
         PROF_MARK(2);
         for (; out.iters < ITER_MAX && more; ++out.iters) {
             scan_lines<HAS_EPS>(z, w, eps);            // north -> south and south -> north
             transpose(w, T, lane);
+            hl = w[0];                                 // (pinned: the same every time)
+            hr = w[WN - 1];
             or_changed(mv_c1, w[1], c1_prev);          // columns: what the vertical scans (and
             or_changed(mv_c62, w[FT], c62_prev);       // the last check) did to them
             c1_prev = w[1];
@@ -426,27 +429,30 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
             if (south & 1ull) out.dirs |= 1u << 5;                                 // SW
             if (south & (1ull << (WN - 1))) out.dirs |= 1u << 7;                   // SE
         }
-        // Columns: lane 0 holds the west halo column, lane 1 my column 1 (lane 63 / 62
-        // for the east); row r of the halo is tested against rows r-1, r, r+1.
+        // Columns, as vectors with lane = row: c1_prev / c62_prev are my final edge columns
+        // (the loop ends on a check that changed nothing, so the copies taken after the
+        // last horizontal scan are final), hl / hr the halo columns.  Row r of the halo is
+        // tested against my rows r-1, r, r+1; rows 0 and 63 of my columns are halo cells
+        // of other tiles and do not count.
         const bool col1_moved = mv_c1 != 0, col62_moved = mv_c62 != 0;
-        if (col1_moved || col62_moved) {
-            unsigned long long side = 0;   // bit 0: west halo can drop, bit 63: east halo
-            // q[r] = my edge column next to this lane's halo column (lane 0 <- lane 1,
-            // lane 63 <- lane 62); the other lanes compute values that are masked off
-            float q_prev = HDEM_INF;
-            float q_cur = lane == 0 ? lane_next(w[1]) : lane_prev(w[1]);
-#pragma unroll
-            for (int r = 1; r <= FT; ++r) {
-                float q_next = HDEM_INF;
-                if (r < FT) q_next = lane == 0 ? lane_next(w[r + 1]) : lane_prev(w[r + 1]);
-                float c = fminf(fminf(q_prev, q_cur), q_next);
-                if (HAS_EPS) c = c + eps;
-                or_less(side, c, w[r]);
-                q_prev = q_cur;
-                q_cur = q_next;
-            }
-            if (col1_moved && (side & 1ull)) out.dirs |= 1u << 3;                  // W
-            if (col62_moved && (side & (1ull << (WN - 1)))) out.dirs |= 1u << 4;   // E
+        if (more) {
+            // cut short by the iteration cap: the columns may have moved after the copies
+            // were taken -- wake without the test (rare, and the tile runs again anyway)
+            if (col1_moved) out.dirs |= 1u << 3;
+            if (col62_moved) out.dirs |= 1u << 4;
+        } else if (col1_moved || col62_moved) {
+            const float m1 = inner ? c1_prev : HDEM_INF, m62 = inner ? c62_prev : HDEM_INF;
+            const float pw = lane == 0 ? HDEM_INF : lane_prev(m1);
+            const float nx = lane == WN - 1 ? HDEM_INF : lane_next(m1);
+            const float pe = lane == 0 ? HDEM_INF : lane_prev(m62);
+            const float ne = lane == WN - 1 ? HDEM_INF : lane_next(m62);
+            float cwest = fminf(fminf(m1, pw), nx), ceast = fminf(fminf(m62, pe), ne);
+            if (HAS_EPS) { cwest += eps; ceast += eps; }
+            unsigned long long west = 0, east = 0;
+            or_less(west, cwest, hl);
+            or_less(east, ceast, hr);
+            if (col1_moved && (west & mid)) out.dirs |= 1u << 3;                  // W
+            if (col62_moved && (east & mid)) out.dirs |= 1u << 4;                 // E
         }
         PROF_MARK(5);
     }
