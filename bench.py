@@ -205,7 +205,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearse else "nccl")
         H = N * S
-        g0, g1, top, bottom = P.local_range(rank, world, H)
+        ghost = P.ghost_rows(world, H)                  # one tile row of overlap per seam
+        g0, g1, top, bottom = P.local_range(rank, world, H, ghost)
         z = oracle.synth_dem(H, S, row0=g0, rows=g1 - g0)
         dev = torch.device("cuda", local_rank)
         zt = torch.from_numpy(z).to(dev)
@@ -217,7 +218,8 @@ def main():
 
         def step():
             # (the last verifying pass of the fill writes the D8 codes of the block)
-            _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt, d8_out=dt_)
+            _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt, d8_out=dt_,
+                                           ghost=ghost)
             info.update(st)
 
         def sync():

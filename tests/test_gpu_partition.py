@@ -32,17 +32,18 @@ def _worker(rank, world, port, H, W, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        g0, g1, _, _ = P.local_range(rank, world, H)
+        ghost = P.ghost_rows(world, H)                     # one tile row of overlap
+        g0, g1, _, _ = P.local_range(rank, world, H, ghost)
         z = oracle.synth_dem(H, W, row0=g0, rows=g1 - g0)
         zt = torch.from_numpy(z).cuda()
         solver = P.HipLocalSolver(0)
         d = torch.empty(zt.shape, dtype=torch.uint8, device=zt.device)
-        w, info = P.sinkfill_distributed(zt, rank, world, solver, d8_out=d)
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, d8_out=d, ghost=ghost)
         torch.cuda.synchronize()
-        own_ = P.owned_slice(rank, world)
+        own_ = P.owned_slice(rank, world, ghost)
         assert torch.equal(d[own_], P.d8_distributed(w, solver)[own_])
         torch.cuda.synchronize()
-        own = P.owned_slice(rank, world)
+        own = own_
         # the one-exchange stencils: groves x3 (21-row halo), box mean (1 row)
         r0, r1 = P.row_range(rank, world, H)
         img = torch.from_numpy(oracle.synth_dem(H, W, pits=False)[r0:r1].copy()).cuda()

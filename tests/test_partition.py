@@ -92,12 +92,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=4):
+def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=4, ghost=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g0, g1, _, _ = P.local_range(rank, world, H)
+        ghost = P.ghost_rows(world, H, ghost)
+        g0, g1, _, _ = P.local_range(rank, world, H, ghost)
         z = oracle.synth_dem(H, W, row0=g0, rows=g1 - g0, variant=variant)
         if nodata:
             full = oracle.synth_dem(H, W, variant=variant)
@@ -107,10 +108,10 @@ def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=
         solver = NumpyLocalSolver()
         d = torch.empty(zt.shape, dtype=torch.uint8)
         w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps,
-                                         coarse_block=coarse_block, d8_out=d)
-        assert torch.equal(d[P.owned_slice(rank, world)],
-                           P.d8_distributed(w, solver)[P.owned_slice(rank, world)])
-        own = P.owned_slice(rank, world)
+                                         coarse_block=coarse_block, d8_out=d, ghost=ghost)
+        assert torch.equal(d[P.owned_slice(rank, world, ghost)],
+                           P.d8_distributed(w, solver)[P.owned_slice(rank, world, ghost)])
+        own = P.owned_slice(rank, world, ghost)
         np.savez(os.path.join(outdir, f"r{rank}.npz"), w=w.numpy()[own], d=d.numpy()[own],
                  exchanges=info["exchanges"])
     finally:
@@ -137,6 +138,18 @@ def test_coarse_fill_bounds_the_fine_fill_from_above(block, nodata):
     assert np.isfinite(up).all()
 
 
+@pytest.mark.parametrize("world,H,W,eps,variant,nodata,coarse_block,ghost", [
+    (2, 96, 80, 0.0, "rough", False, 4, 7),        # 7 rows of overlap, one of them pinned
+    (3, 99, 70, 0.0, "rough", True, 4, 62),        # asks for 62, gets what the blocks allow (32)
+    (2, 64, 48, 1e-3, "rough", False, 4, 5),
+    (3, 75, 70, 0.0, "srtm", False, 8, 3),
+])
+def test_partitioned_fill_with_overlap_rows(tmp_path, world, H, W, eps, variant, nodata,
+                                            coarse_block, ghost):
+    test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata,
+                                                     coarse_block, ghost)
+
+
 @pytest.mark.parametrize("world,H,W,eps,variant,nodata,coarse_block", [
     (2, 96, 80, 0.0, "rough", False, 4),
     (2, 101, 64, 0.0, "srtm", False, 4),
@@ -148,10 +161,10 @@ def test_coarse_fill_bounds_the_fine_fill_from_above(block, nodata):
     (3, 75, 70, 0.0, "srtm", False, 8),
 ])
 def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata,
-                                                     coarse_block):
+                                                     coarse_block, ghost=1):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, H, W, eps, variant, nodata, str(tmp_path),
-                            coarse_block), nprocs=world, join=True)
+                            coarse_block, ghost), nprocs=world, join=True)
     z = oracle.synth_dem(H, W, variant=variant)
     if nodata:
         z[H // 2 - 3:H // 2 + 3, 10:20] = np.nan
@@ -213,3 +226,7 @@ def test_row_ranges_tile_the_raster():
                 g0, g1, top, bot = P.local_range(r, world, H)
                 assert (top, bot) == (r > 0, r < world - 1)
                 assert g0 == rows[r][0] - top and g1 == rows[r][1] + bot
+                g = P.ghost_rows(world, H)
+                assert 1 <= g <= max(1, H // world - 1) and (world == 1 or g <= P.GHOST_ROWS)
+                g0, g1, _, _ = P.local_range(r, world, H, g)
+                assert g0 >= 0 and g1 <= H and g0 == rows[r][0] - g * top
