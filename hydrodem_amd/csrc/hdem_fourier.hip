@@ -307,6 +307,31 @@ __global__ __launch_bounds__(NT) void quadrant_abs_kernel(const float2 *__restri
 // Out of place: q_out <- q * (1 - hit) (may be NULL: the second pass only needs the mask).
 constexpr int HT = 256;
 
+// Inclusive prefix sum over the 64 lanes of a wave, float64, with DPP lane moves instead
+// of LDS-crossbar shuffles: four shifts inside each row of 16 lanes (lanes without a source
+// add 0), then lane 15 of rows 0 and 2 broadcast into rows 1 and 3, then lane 31 into the
+// upper half (gfx9 row_shr / row_bcast).  A double moves as its two 32-bit halves.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xF,
+                                               ROW_MASK == 0xF);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_scan_f64(double p)
+{
+    p += dpp_move_f64<0x111, 0xF>(p);      // row_shr:1
+    p += dpp_move_f64<0x112, 0xF>(p);      // row_shr:2
+    p += dpp_move_f64<0x114, 0xF>(p);      // row_shr:4
+    p += dpp_move_f64<0x118, 0xF>(p);      // row_shr:8
+    p += dpp_move_f64<0x142, 0xA>(p);      // row_bcast:15 -> rows 1 and 3
+    p += dpp_move_f64<0x143, 0xC>(p);      // row_bcast:31 -> rows 2 and 3
+    return p;
+}
+
 template <int R, int r>
 __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restrict__ q, int h, int w,
                                                            float factor, int seg,
@@ -351,12 +376,7 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
             if (y >= y1) break;                                   // uniform over the block
             const int buf = u & 1;
             // inclusive scan of cb over the 256 lanes
-            double p = cb;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const double up = __shfl_up(p, o);
-                if (lane >= o) p += up;
-            }
+            double p = wave_scan_f64(cb);
             if (lane == 63) wtot[buf][wave] = p;
             sml[buf][tid] = cs;
             __syncthreads();
