@@ -1020,7 +1020,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                                          : (int64_t)COARSE_MIN_CELLS)) {
             // fill the block-maximum raster first: 1/256 of the cells, and every level in
             // it bounds the fine fill of its block from above
-            const int b = 1 << COARSE_SHIFT, ch = (H + b - 1) / b, cwid = (W + b - 1) / b;
+            const int cshift = getenv("HDEM_COARSE_SHIFT") ? atoi(getenv("HDEM_COARSE_SHIFT")) : COARSE_SHIFT;
+            const int b = 1 << cshift, ch = (H + b - 1) / b, cwid = (W + b - 1) / b;
             const size_t need = (size_t)2 * ch * cwid * sizeof(float);
             if (ctx->coarse_bytes < need) {
                 if (ctx->coarse_buf) {
@@ -1043,7 +1044,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             if (rc) return rc;
             coarse = cfill;
             coarse_cw = cwid;
-            coarse_shift = COARSE_SHIFT;
+            coarse_shift = cshift;
         }
     }
     ctx->start_coarse = nullptr;                // a caller's coarse raster is used once
