@@ -5,8 +5,8 @@
 // rasters and byte masks; all results are selections, comparisons and (one) small
 // fixed-order float32 mean, so every kernel is bit-exact against the reference.
 //
-// HBM-bound except the majority vote, which is LDS-bound: ws^2 - 4 reads per vote
-// pass, two passes (Boyer-Moore candidate, then its count).
+// HBM-bound except the majority vote, which is VALU-bound (a separable Boyer-Moore vote
+// out of LDS, then a count pass where the vote allows the share).
 #include <cstring>
 
 #include "hdem_internal.h"
@@ -53,45 +53,83 @@ __global__ __launch_bounds__(NT) void correct_nan_kernel(const float *__restrict
 
 // MajorityFilter.apply (:44-73): the value held by more than 70 % of (ws^2 - 1) cells of
 // the ws x ws window minus its corners, else 0; only centres whose window fits.  A value
-// with that share is a strict majority, so Boyer-Moore finds it; the second pass counts.
-constexpr int MTX = 64, MTY = 16, MMAX = 15;
+// with that share is a strict majority, so a Boyer-Moore vote finds it and a count pass
+// confirms it.  The vote is separable: a (candidate, votes) summary stands for "votes
+// copies of candidate plus pairs of distinct values", two summaries merge into one of
+// their union, so each row segment is voted once (ws steps) and shared by the ws windows
+// above and below it, which merge ws row summaries each: ~2.3 ws steps per cell instead
+// of ws^2.  A value present c times among n cells leaves votes >= 2c - n, so the count
+// pass only runs where the votes allow the share.  NaN never equals anything, the way
+// every NaN is its own key in the reference's Counter.
+constexpr int MTX = 64, MTY = 32, MMAX = 15;
 
-__global__ __launch_bounds__(NT) void majority_kernel(const float *__restrict__ in, int h, int w,
-                                                      int ws, int need, float *__restrict__ out)
+__device__ __forceinline__ void vote_step(float v, float &cand, int &votes)
 {
-    __shared__ float s[(MTY + MMAX - 1) * (MTX + MMAX - 1)];
-    const int r = ws / 2, tw = MTX + 2 * r, th = MTY + 2 * r;
+    const int t = votes + (v == cand ? 1 : -1);
+    cand = t < 0 ? v : cand;
+    votes = t < 0 ? -t : t;
+}
+
+__device__ __forceinline__ void vote_merge(float c2, int v2, float &cand, int &votes)
+{
+    const int t = votes + (c2 == cand ? v2 : -v2);
+    cand = t < 0 ? c2 : cand;
+    votes = t < 0 ? -t : t;
+}
+
+template <int WS>
+__global__ __launch_bounds__(NT) void majority_kernel(const float *__restrict__ in, int h, int w,
+                                                      int need, float *__restrict__ out)
+{
+    constexpr int R = WS / 2, TW = MTX + 2 * R, TH = MTY + 2 * R, CELLS = WS * WS - 4;
+    __shared__ float s[TH * TW];
+    __shared__ float cand_full[TH * MTX], cand_inner[TH * MTX];   // columns x-R..x+R / x-R+1..x+R-1
+    __shared__ int votes_both[TH * MTX];                          // full | inner << 16
     const int x0 = blockIdx.x * MTX, y0 = blockIdx.y * MTY;
-    for (int k = threadIdx.x; k < tw * th; k += NT) {
-        const int ly = k / tw, lx = k - ly * tw;
-        const int gy = y0 - r + ly, gx = x0 - r + lx;
+    for (int k = threadIdx.x; k < TW * TH; k += NT) {
+        const int ly = k / TW, lx = k - ly * TW;
+        const int gy = y0 - R + ly, gx = x0 - R + lx;
         s[k] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(size_t)gy * w + gx]
                                                         : __builtin_nanf("");
     }
     __syncthreads();
     const int lx = threadIdx.x % MTX;
+    for (int ly = threadIdx.x / MTX; ly < TH; ly += NT / MTX) {
+        const float *row = s + ly * TW + lx;
+        float cand = 0.0f;
+        int votes = 0;
+#pragma unroll
+        for (int dx = 1; dx < WS - 1; ++dx) vote_step(row[dx], cand, votes);
+        cand_inner[ly * MTX + lx] = cand;
+        const int inner = votes;
+        vote_step(row[0], cand, votes);
+        vote_step(row[WS - 1], cand, votes);
+        cand_full[ly * MTX + lx] = cand;
+        votes_both[ly * MTX + lx] = votes | (inner << 16);
+    }
+    __syncthreads();
     for (int ly = threadIdx.x / MTX; ly < MTY; ly += NT / MTX) {
         const int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
         float result = 0.0f;
-        if (y >= r && y < h - r && x >= r && x < w - r) {
-            float cand = 0.0f;
-            int votes = 0;
-            for (int dy = 0; dy < ws; ++dy)
-                for (int dx = 0; dx < ws; ++dx) {
-                    if ((dy == 0 || dy == ws - 1) && (dx == 0 || dx == ws - 1)) continue;
-                    const float v = s[(ly + dy) * tw + lx + dx];
-                    if (votes == 0) { cand = v; votes = 1; }
-                    else votes += (v == cand) ? 1 : -1;
-                }
-            // a value present c times leaves at least 2c - cells votes: no count pass
-            // where the vote already rules the share out
-            if (votes >= 2 * need - (ws * ws - 4)) {
+        if (y >= R && y < h - R && x >= R && x < w - R) {
+            float cand = cand_inner[ly * MTX + lx];
+            int votes = votes_both[ly * MTX + lx] >> 16;
+#pragma unroll
+            for (int dy = 1; dy < WS - 1; ++dy)
+                vote_merge(cand_full[(ly + dy) * MTX + lx], votes_both[(ly + dy) * MTX + lx] & 0xffff,
+                           cand, votes);
+            vote_merge(cand_inner[(ly + WS - 1) * MTX + lx], votes_both[(ly + WS - 1) * MTX + lx] >> 16,
+                       cand, votes);
+            if (votes >= 2 * need - CELLS) {
+                const float *win = s + ly * TW + lx;
                 int count = 0;
-                for (int dy = 0; dy < ws; ++dy)
-                    for (int dx = 0; dx < ws; ++dx) {
-                        if ((dy == 0 || dy == ws - 1) && (dx == 0 || dx == ws - 1)) continue;
-                        count += s[(ly + dy) * tw + lx + dx] == cand;
+#pragma unroll
+                for (int dy = 0; dy < WS; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < WS; ++dx) {
+                        if ((dy == 0 || dy == WS - 1) && (dx == 0 || dx == WS - 1)) continue;
+                        count += win[dy * TW + dx] == cand;
                     }
                 if (count >= need) result = cand;
             }
@@ -167,25 +205,9 @@ __global__ __launch_bounds__(NT) void nonzero_kernel(const float *__restrict__ i
 }
 
 // img * mask (ProductFilter with the byte mask of ExpandFilter)
-__global__ __launch_bounds__(NT) void mask_product_kernel(const float *__restrict__ img,
-                                                          const uint8_t *__restrict__ m, size_t n,
-                                                          float *__restrict__ out)
-{
-    const size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4;
-    if (i + 4 <= n) {
-        const hdem_f4 v = hdem_ld4u(img + i);
-        const unsigned b = *(const unsigned *)(m + i);
-        const hdem_f4 r = {v[0] * ((b & 0xffu) ? 1.0f : 0.0f), v[1] * ((b & 0xff00u) ? 1.0f : 0.0f),
-                           v[2] * ((b & 0xff0000u) ? 1.0f : 0.0f),
-                           v[3] * ((b & 0xff000000u) ? 1.0f : 0.0f)};
-        hdem_st4u(out + i, r);
-    } else {
-        for (size_t k = i; k < n; ++k) out[k] = img[k] * (m[k] ? 1.0f : 0.0f);
-    }
-}
-
 __device__ __forceinline__ int reflect(int i, int n)
 {   // scipy mode='reflect': d c b a | a b c d | d c b a
+    if (i >= 0 && i < n) return i;
     if (n == 1) return 0;
     const int p = 2 * n;
     i %= p;
@@ -194,16 +216,22 @@ __device__ __forceinline__ int reflect(int i, int n)
 }
 
 // scipy.ndimage.grey_dilation(size=(sy, sx)), odd sizes: maximum over the centred window,
-// mode='reflect'.  64 x 16 outputs per block from an LDS tile; the reflection is resolved
-// once per loaded cell, the sy * sx taps are plain LDS reads.
-constexpr int GTX = 64, GTY = 16;
+// mode='reflect'.  64 x 32 outputs per block from an LDS tile; the reflection is resolved
+// once per loaded cell.  The maximum is separable: row maxima of the tile first (sx LDS
+// reads per tile cell), then sy reads down the columns.  A NaN is never "greater", so it
+// only survives at the centre, like the one-pass form.  CSY / CSX > 0: sizes known at
+// compile time (7 x 7 is the only size the reference uses), 0: run-time sizes.
+constexpr int GTX = 64, GTY = 32;
 
+template <int CSY, int CSX>
 __global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restrict__ in, int h,
-                                                           int w, int sy, int sx,
+                                                           int w, int sy_, int sx_,
                                                            float *__restrict__ out)
 {
     extern __shared__ float tile[];
+    const int sy = CSY ? CSY : sy_, sx = CSX ? CSX : sx_;
     const int ry = sy / 2, rx = sx / 2, tw = GTX + 2 * rx, th = GTY + 2 * ry;
+    float *rowmax = tile + tw * th;                 // th x GTX
     const int x0 = blockIdx.x * GTX, y0 = blockIdx.y * GTY;
     for (int k = threadIdx.x; k < tw * th; k += NT) {
         const int ly = k / tw, lx = k - ly * tw;
@@ -211,15 +239,25 @@ __global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restri
     }
     __syncthreads();
     const int lx = threadIdx.x % GTX;
+    for (int ly = threadIdx.x / GTX; ly < th; ly += NT / GTX) {
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int dx = 0; dx < sx; ++dx) {
+            const float v = tile[ly * tw + lx + dx];
+            m = v > m ? v : m;
+        }
+        rowmax[ly * GTX + lx] = m;
+    }
+    __syncthreads();
     for (int ly = threadIdx.x / GTX; ly < GTY; ly += NT / GTX) {
         const int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
-        float m = tile[ly * tw + lx];
-        for (int dy = 0; dy < sy; ++dy)
-            for (int dx = 0; dx < sx; ++dx) {
-                const float v = tile[(ly + dy) * tw + lx + dx];
-                if (v > m) m = v;
-            }
+        float m = tile[(ly + ry) * tw + lx + rx];
+#pragma unroll
+        for (int dy = 0; dy < sy; ++dy) {
+            const float v = rowmax[(ly + dy) * GTX + lx];
+            m = v > m ? v : m;
+        }
         out[(size_t)y * w + x] = m;
     }
 }
@@ -234,6 +272,115 @@ __global__ __launch_bounds__(NT) void positive_kernel(const float *__restrict__ 
                                  ((unsigned)(v[2] > 0.0f) << 16) | ((unsigned)(v[3] > 0.0f) << 24);
     } else {
         for (size_t k = i; k < n; ++k) out[k] = in[k] > 0.0f;
+    }
+}
+
+// TidyingLagoons.apply (:564-610) in one pass: erode (img != 0) twice with the 3 x 3
+// cross, ExpandFilter(7), multiply with img, 7 x 7 grey dilation -- reach 2 + 3 + 3 = 8
+// cells.  A block owns 48 x 64 outputs inside a 64 x 80 tile, one wave lane per tile
+// column, so a tile row of a binary stage is one 64-bit word (the wave's ballot) and the
+// morphology is shifts and ands of whole rows, one thread per row:
+//   two erosions by the cross = one by the radius-2 diamond (cells outside the raster 0),
+//   the expand window = rows -3, +3 five wide, rows -2..+2 seven wide (square minus its
+//   corners), only centres whose window fits.
+// Cells outside the raster hold the reflected cell for the dilation; the expand mask is
+// 0 within 3 cells of the border, so their product is img * 0 like the cell they mirror.
+// positive != NULL: MaskPositives of the result as well (LagoonsDetection).
+constexpr int FTX = 48, FTY = 64, FREACH = 8, FTW = 64, FTH = FTY + 2 * FREACH;
+typedef unsigned long long rowbits;
+
+__device__ __forceinline__ rowbits all3(rowbits m) { return m & (m << 1) & (m >> 1); }
+__device__ __forceinline__ rowbits any5(rowbits m)
+{
+    return m | (m << 1) | (m >> 1) | (m << 2) | (m >> 2);
+}
+
+__global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict__ in, int h, int w,
+                                                        float *__restrict__ out,
+                                                        uint8_t *__restrict__ positive)
+{
+    static_assert(FTW == 64 && FTX + 2 * FREACH == FTW, "one wave lane per tile column");
+    __shared__ float ti[FTH * FTW], rowmax[FTH * FTW];
+    __shared__ rowbits nz[FTH], eroded[FTH], expanded[FTH];
+    const int x0 = blockIdx.x * FTX - FREACH, y0 = blockIdx.y * FTY - FREACH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gx = x0 + lane;
+    {   // all loads of the thread in flight before the first ballot waits for one
+        constexpr int ROWS = FTH / (NT / 64);
+        static_assert(FTH % (NT / 64) == 0, "tile rows split evenly over the waves");
+        const int rx = reflect(gx, w);
+        float v[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k)
+            v[k] = in[(size_t)reflect(y0 + wave + k * (NT / 64), h) * w + rx];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const int ly = wave + k * (NT / 64), gy = y0 + ly;
+            ti[ly * FTW + lane] = v[k];
+            const rowbits m = __ballot(gy >= 0 && gy < h && gx >= 0 && gx < w && v[k] != 0.0f);
+            if (lane == 0) nz[ly] = m;
+        }
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    if (r < FTH) {
+        rowbits e = 0;
+        if (r >= 2 && r < FTH - 2) {
+            const rowbits c = nz[r];
+            e = nz[r - 2] & all3(nz[r - 1]) & all3(c) & (c << 2) & (c >> 2) & all3(nz[r + 1]) &
+                nz[r + 2];
+        }
+        eroded[r] = e;
+    }
+    __syncthreads();
+    if (r < FTH) {
+        rowbits x = 0;
+        const int gy = y0 + r;
+        if (r >= 5 && r < FTH - 5 && gy >= 3 && gy < h - 3) {
+            rowbits wide = eroded[r - 2] | eroded[r - 1] | eroded[r] | eroded[r + 1] | eroded[r + 2];
+            wide = any5(wide) | (wide << 3) | (wide >> 3);
+            x = wide | any5(eroded[r - 3] | eroded[r + 3]);
+            const int lo = max(0, 3 - x0), hi = min(64, w - 3 - x0);      // window fits: [lo, hi)
+            const rowbits upto_hi = hi >= 64 ? ~0ull : hi <= 0 ? 0ull : (1ull << hi) - 1;
+            const rowbits below_lo = lo >= 64 ? ~0ull : (1ull << lo) - 1;
+            x &= upto_hi & ~below_lo;
+        }
+        expanded[r] = x;
+    }
+    __syncthreads();
+    for (int ly = wave; ly < FTH; ly += NT / 64)
+        ti[ly * FTW + lane] *= (expanded[ly] >> lane) & 1 ? 1.0f : 0.0f;
+    __syncthreads();
+    if (lane >= 3 && lane < FTW - 3)
+        for (int ly = 5 + wave; ly < FTH - 5; ly += NT / 64) {
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int dx = -3; dx <= 3; ++dx) {
+                const float v = ti[ly * FTW + lane + dx];
+                m = v > m ? v : m;
+            }
+            rowmax[ly * FTW + lane] = m;
+        }
+    __syncthreads();
+    if (lane < FREACH || lane >= FTW - FREACH || gx >= w) return;
+    // each wave takes FTY / 4 consecutive rows and keeps the 7 row maxima in registers
+    constexpr int PER = FTY / (NT / 64);
+    const int first = FREACH + wave * PER;
+    float win[7];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) win[k + 1] = rowmax[(first - 3 + k) * FTW + lane];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int ly = first + k, gy = y0 + ly;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
+        win[6] = rowmax[(ly + 3) * FTW + lane];
+        if (gy >= h) break;
+        float m = ti[ly * FTW + lane];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m = win[j] > m ? win[j] : m;
+        out[(size_t)gy * w + gx] = m;
+        if (positive) positive[(size_t)gy * w + gx] = m > 0.0f;
     }
 }
 
@@ -322,8 +469,17 @@ extern "C" int hdem_majority_f32_dev(hdem_ctx *ctx, const float *img, int H, int
     while ((double)need <= thr) ++need;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_MAJORITY, (int64_t)H * W);
-        hipLaunchKernelGGL(majority_kernel, dim3((W + MTX - 1) / MTX, (H + MTY - 1) / MTY), dim3(NT),
-                           0, ctx->stream, img, H, W, window, need, out);
+        const dim3 grid((W + MTX - 1) / MTX, (H + MTY - 1) / MTY);
+        switch (window) {
+#define HDEM_MAJORITY(WS_)                                                                     \
+    case WS_:                                                                                  \
+        hipLaunchKernelGGL(majority_kernel<WS_>, grid, dim3(NT), 0, ctx->stream, img, H, W,   \
+                           need, out);                                                         \
+        break;
+            HDEM_MAJORITY(3) HDEM_MAJORITY(5) HDEM_MAJORITY(7) HDEM_MAJORITY(9)
+            HDEM_MAJORITY(11) HDEM_MAJORITY(13) HDEM_MAJORITY(15)
+#undef HDEM_MAJORITY
+        }
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
@@ -381,48 +537,29 @@ extern "C" int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     {
         hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)H * W);
-        hipLaunchKernelGGL(grey_dilation_kernel, dim3((W + GTX - 1) / GTX, (H + GTY - 1) / GTY),
-                           dim3(NT), (GTX + sx - 1) * (GTY + sy - 1) * sizeof(float), ctx->stream,
-                           img, H, W, sy, sx, out);
+        const dim3 grid((W + GTX - 1) / GTX, (H + GTY - 1) / GTY);
+        const size_t lds = (size_t)(GTX + sx - 1 + GTX) * (GTY + sy - 1) * sizeof(float);
+        if (sy == 7 && sx == 7)
+            hipLaunchKernelGGL((grey_dilation_kernel<7, 7>), grid, dim3(NT), lds, ctx->stream, img,
+                               H, W, sy, sx, out);
+        else
+            hipLaunchKernelGGL((grey_dilation_kernel<0, 0>), grid, dim3(NT), lds, ctx->stream, img,
+                               H, W, sy, sx, out);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }
 
-// TidyingLagoons.apply (:564-610): erode (img != 0) twice, expand 7, multiply with img,
-// 7 x 7 grey dilation.  scratch: 2 byte rasters + 1 float raster (6 bytes per cell).
 static size_t round16(size_t n) { return (n + 15) / 16 * 16; }
 
-static int tidying(hdem_ctx *ctx, const float *img, int H, int W, float *out, char *scratch)
+static int tidying(hdem_ctx *ctx, const float *img, int H, int W, float *out, uint8_t *positive)
 {
-    const size_t n = (size_t)H * W;
-    uint8_t *a = (uint8_t *)scratch, *b = a + round16(n);
-    float *f = (float *)(b + round16(n));
-    morph_struct st;
-    if (int rc = make_struct(CROSS, 3, 3, &st)) return rc;
-    hipStream_t s = ctx->stream;
-    const unsigned blocks = (unsigned)((n + 4 * NT - 1) / (4 * NT));
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n);
-        hipLaunchKernelGGL(nonzero_kernel, dim3(blocks), dim3(NT), 0, s, img, n, a);
-    }
-    // a -> b -> a : two erosions, the result back in a
-    if (int rc = erode_n(ctx, a, H, W, st, 1, nullptr, b)) return rc;
-    if (int rc = erode_n(ctx, b, H, W, st, 1, nullptr, a)) return rc;
-    if (int rc = hdem_expand_u8_dev(ctx, a, H, W, 7, b)) return rc;
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n * 2);
-        hipLaunchKernelGGL(mask_product_kernel, dim3(blocks), dim3(NT), 0, s, img,
-                           (const uint8_t *)b, n, f);
-        hipLaunchKernelGGL(grey_dilation_kernel, dim3((W + GTX - 1) / GTX, (H + GTY - 1) / GTY),
-                           dim3(NT), (GTX + 6) * (GTY + 6) * sizeof(float), s, (const float *)f, H,
-                           W, 7, 7, out);
-    }
+    hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)H * W);
+    hipLaunchKernelGGL(tidy_fused_kernel, dim3((W + FTX - 1) / FTX, (H + FTY - 1) / FTY), dim3(NT),
+                       0, ctx->stream, img, H, W, out, positive);
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }
-
-static size_t tidying_scratch(size_t n) { return 2 * round16(n) + round16(n * sizeof(float)); }
 
 extern "C" int hdem_tidying_lagoons_f32_dev(hdem_ctx *ctx, const float *img, int H, int W,
                                             float *out)
@@ -432,9 +569,7 @@ extern "C" int hdem_tidying_lagoons_f32_dev(hdem_ctx *ctx, const float *img, int
     HDEM_REQUIRE(img != out, HDEM_ERR_BAD_ARG, "tidying cannot run in place");
     if (int rc = window_ok(7, H, W)) return rc;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
-    char *scratch = (char *)hdem_arena(ctx, tidying_scratch((size_t)H * W));
-    if (!scratch) return HDEM_ERR_OOM;
-    return tidying(ctx, img, H, W, out, scratch);
+    return tidying(ctx, img, H, W, out, nullptr);
 }
 
 // LagoonsDetection.apply (:613-661): CorrectNANValues -> MajorityFilter(11) ->
@@ -448,19 +583,14 @@ extern "C" int hdem_lagoons_detection_f32_dev(hdem_ctx *ctx, const float *hsheds
     if (int rc = window_ok(11, H, W)) return rc;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t n = (size_t)H * W, fbytes = round16(n * sizeof(float));
-    char *scratch = (char *)hdem_arena(ctx, 3 * fbytes + tidying_scratch(n));
+    char *scratch = (char *)hdem_arena(ctx, 3 * fbytes);
     if (!scratch) return HDEM_ERR_OOM;
     float *major = (float *)scratch;
     if (!fixed) fixed = (float *)(scratch + fbytes);
     if (!values) values = (float *)(scratch + 2 * fbytes);
     if (int rc = hdem_correct_nan_f32_dev(ctx, hsheds, H, W, fixed)) return rc;
     if (int rc = hdem_majority_f32_dev(ctx, fixed, H, W, 11, major)) return rc;
-    if (int rc = tidying(ctx, major, H, W, values, scratch + 3 * fbytes)) return rc;
-    {
-        hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)n);
-        hipLaunchKernelGGL(positive_kernel, dim3((unsigned)((n + 4 * NT - 1) / (4 * NT))), dim3(NT), 0,
-                           ctx->stream, (const float *)values, n, mask);
-    }
+    if (int rc = tidying(ctx, major, H, W, values, mask)) return rc;
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }

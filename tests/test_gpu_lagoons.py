@@ -79,6 +79,23 @@ def test_larger_raster_against_the_oracle(shape):
                           stages["MajorityFilter"])
 
 
+@pytest.mark.parametrize("window", [3, 5, 7, 9, 11, 13, 15])
+def test_majority_near_the_share_threshold(window):
+    """Few distinct values whose share hovers around 70 %, voids in between: the
+    separable vote must name the same winners as a full count (oracle), window by
+    window, for every window size the kernel is built for."""
+    rng = np.random.default_rng([20240611, window])
+    h, w_ = 203, 331                                  # not multiples of the 64 x 32 tile
+    img = np.where(rng.random((h, w_)) < 0.74, 5.0, rng.integers(1, 4, (h, w_))).astype(np.float32)
+    img[rng.random((h, w_)) < 0.01] = np.nan
+    img[60:140, 100:260] = np.where(rng.random((80, 160)) < 0.9, -3.0, 5.0)
+    want = L.majority_filter(img, window=window)
+    got = hd.MajorityFilter(window_size=window).apply(img)
+    assert np.array_equal(got, want)
+    if window > 3:
+        assert 0 < np.count_nonzero(want) < want.size
+
+
 def test_error_behaviour():
     with pytest.raises(hd.WindowSizeHighError):
         hd.MajorityFilter(window_size=11).apply(np.zeros((8, 30), dtype=np.float32))
