@@ -90,6 +90,31 @@ def test_destripe_full_size_properties():
     assert abs(out.mean(dtype=np.float64) - dem.mean(dtype=np.float64)) < 1e-3
 
 
+def test_lagoons_full_size_on_crops():
+    """LagoonsDetection at 16384^2 against the oracle on crops: the chain is local
+    (reach 1 + 5 + 8 cells), so a crop reproduces every cell further than that from
+    its cut sides; corner crops keep the raster's own border, which must match too."""
+    from oracle import hdem_oracle_lagoons as L
+    hs = np.round(oracle.synth_dem(N, N))
+    hs[::97, ::89] = -32768.0                                  # voids
+    hs[5000:5400, 7000:7600] = 212.0                           # a lake across tile seams
+    hs[:40, :300] = 95.0                                       # and one on the raster's border
+    mask, fixed, values = [r.to_host() for r in
+                           backend.lagoons_detection_dev(backend.DeviceRaster.from_host(hs))]
+    assert mask.sum() > 400 * 600 // 2
+    reach, c = 14, 320
+    rng = np.random.default_rng(3)
+    spots = [(0, 0), (0, N - c), (N - c, 0), (N - c, N - c), (4900, 6900), (5250, 7450)]
+    spots += [(int(rng.integers(0, N - c)), int(rng.integers(0, N - c))) for _ in range(3)]
+    for y0, x0 in spots:
+        sl = (slice(y0, y0 + c), slice(x0, x0 + c))
+        want_mask, stages = L.lagoons_detection(hs[sl].copy())
+        inner = (slice(0 if y0 == 0 else reach, c if y0 + c == N else c - reach),
+                 slice(0 if x0 == 0 else reach, c if x0 + c == N else c - reach))
+        assert np.array_equal(fixed[sl][inner], stages["CorrectNANValues"][inner], equal_nan=True)
+        assert np.array_equal(values[sl][inner], stages["TidyingLagoons"][inner])
+        assert np.array_equal(mask[sl][inner] != 0, want_mask[inner] != 0)
+
 
 @pytest.mark.skipif(__import__("os").environ.get("HDEM_BIG_TESTS") != "1",
                     reason="4 GiB raster: ~5 min of host work; set HDEM_BIG_TESTS=1")
