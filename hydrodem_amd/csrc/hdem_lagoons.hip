@@ -58,83 +58,132 @@ __global__ __launch_bounds__(NT) void correct_nan_kernel(const float *__restrict
 // copies of candidate plus pairs of distinct values", two summaries merge into one of
 // their union, so each row segment is voted once (ws steps) and shared by the ws windows
 // above and below it, which merge ws row summaries each: ~2.3 ws steps per cell instead
-// of ws^2.  A value present c times among n cells leaves votes >= 2c - n, so the count
-// pass only runs where the votes allow the share.  NaN never equals anything, the way
-// every NaN is its own key in the reference's Counter.
+// of ws^2.  A value present c times among n cells leaves 2c - n <= votes <= c, so the
+// count pass only runs where the votes neither prove the share nor rule it out.
+//
+// Values are compared as bit patterns after -0 -> +0 and every NaN -> one pattern.  In
+// the reference every NaN is its own Counter key and never wins; here the NaNs vote
+// together, which cannot unseat a value with the share (they are at most n - need), and
+// a NaN winner becomes "no majority" at the end.
 constexpr int MTX = 64, MTY = 32, MMAX = 15;
+constexpr unsigned NAN_KEY = 0x7fc00000u;
 
-__device__ __forceinline__ void vote_step(float v, float &cand, int &votes)
+__device__ __forceinline__ unsigned vote_key(float v)
 {
-    const int t = votes + (v == cand ? 1 : -1);
-    cand = t < 0 ? v : cand;
-    votes = t < 0 ? -t : t;
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x7fffffffu) > 0x7f800000u ? NAN_KEY : b == 0x80000000u ? 0u : b;
 }
 
-__device__ __forceinline__ void vote_merge(float c2, int v2, float &cand, int &votes)
+// One Boyer-Moore step with the K-th element of a segment, K known at compile time: with
+// q = (votes + K) / 2 a match is q + 1 and a mismatch leaves q alone, and votes can only
+// be 0 (the newcomer becomes the candidate) when K is even -- 3-4 operations per step on
+// average instead of 7.  The candidate is remembered as the column it was seen in
+// (4 bits), so a row summary is 16 bits of LDS -- candidate column and votes, for the
+// full and for the inner segment -- and 8 blocks fit a CU instead of 3 (the kernel waits
+// on its tile loads and on dependent operations, not on an execution unit).
+template <int WS, int K, int END>
+struct vote_run {
+    // cells: the inner columns 1 .. WS-2 first, then columns 0 and WS-1
+    static constexpr int COL = K < WS - 2 ? K + 1 : K == WS - 2 ? 0 : WS - 1;
+    static __device__ __forceinline__ void go(const unsigned *cells, unsigned &cand, unsigned &col,
+                                              unsigned &q)
+    {
+        if (K % 2 == 0) {
+            const bool fresh = q == K / 2;
+            cand = fresh ? cells[K] : cand;
+            col = fresh ? COL : col;
+        }
+        q += cells[K] == cand;
+        vote_run<WS, K + 1, END>::go(cells, cand, col, q);
+    }
+};
+template <int WS, int END>
+struct vote_run<WS, END, END> {
+    static __device__ __forceinline__ void go(const unsigned *, unsigned &, unsigned &, unsigned &) {}
+};
+
+// the summary (c2, v2) merged into (cand, votes)
+__device__ __forceinline__ void vote_merge(unsigned c2, unsigned v2, unsigned &cand, unsigned &votes)
 {
-    const int t = votes + (c2 == cand ? v2 : -v2);
-    cand = t < 0 ? c2 : cand;
-    votes = t < 0 ? -t : t;
+    const bool eq = c2 == cand, take = !eq && v2 > votes;
+    votes = eq ? votes + v2 : __usad(votes, v2, 0u);
+    cand = take ? c2 : cand;
 }
 
 template <int WS>
 __global__ __launch_bounds__(NT) void majority_kernel(const float *__restrict__ in, int h, int w,
                                                       int need, float *__restrict__ out)
 {
+    static_assert(WS <= 15, "columns and votes are packed in 4 bits");
     constexpr int R = WS / 2, TW = MTX + 2 * R, TH = MTY + 2 * R, CELLS = WS * WS - 4;
-    __shared__ float s[TH * TW];
-    __shared__ float cand_full[TH * MTX], cand_inner[TH * MTX];   // columns x-R..x+R / x-R+1..x+R-1
-    __shared__ int votes_both[TH * MTX];                          // full | inner << 16
+    __shared__ unsigned s[TH * TW];
+    // per row segment: full column | full votes << 4 | inner column << 8 | inner votes << 12
+    __shared__ unsigned short summary[TH * MTX];
     const int x0 = blockIdx.x * MTX, y0 = blockIdx.y * MTY;
-    for (int k = threadIdx.x; k < TW * TH; k += NT) {
-        const int ly = k / TW, lx = k - ly * TW;
-        const int gy = y0 - R + ly, gx = x0 - R + lx;
-        s[k] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(size_t)gy * w + gx]
-                                                        : __builtin_nanf("");
+    {   // every load of the thread in flight before the first one is used
+        constexpr int LOADS = (TW * TH + NT - 1) / NT;
+        float v[LOADS];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            const int k = threadIdx.x + j * NT, ly = k / TW, lx = k - ly * TW;
+            const int gy = y0 - R + ly, gx = x0 - R + lx;
+            v[j] = (k < TW * TH && gy >= 0 && gy < h && gx >= 0 && gx < w)
+                       ? in[(size_t)gy * w + gx] : __builtin_nanf("");
+        }
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            const int k = threadIdx.x + j * NT;
+            if (k < TW * TH) s[k] = vote_key(v[j]);
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x % MTX;
     for (int ly = threadIdx.x / MTX; ly < TH; ly += NT / MTX) {
-        const float *row = s + ly * TW + lx;
-        float cand = 0.0f;
-        int votes = 0;
+        const unsigned *row = s + ly * TW + lx;
+        unsigned cells[WS];
 #pragma unroll
-        for (int dx = 1; dx < WS - 1; ++dx) vote_step(row[dx], cand, votes);
-        cand_inner[ly * MTX + lx] = cand;
-        const int inner = votes;
-        vote_step(row[0], cand, votes);
-        vote_step(row[WS - 1], cand, votes);
-        cand_full[ly * MTX + lx] = cand;
-        votes_both[ly * MTX + lx] = votes | (inner << 16);
+        for (int k = 0; k < WS - 2; ++k) cells[k] = row[1 + k];
+        cells[WS - 2] = row[0];
+        cells[WS - 1] = row[WS - 1];
+        unsigned cand = 0, col = 0, q = 0;
+        vote_run<WS, 0, WS - 2>::go(cells, cand, col, q);
+        const unsigned inner = col | ((2 * q - (WS - 2)) << 4);
+        vote_run<WS, WS - 2, WS>::go(cells, cand, col, q);
+        summary[ly * MTX + lx] = (unsigned short)(col | ((2 * q - WS) << 4) | (inner << 8));
     }
     __syncthreads();
     for (int ly = threadIdx.x / MTX; ly < MTY; ly += NT / MTX) {
         const int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
-        float result = 0.0f;
+        unsigned result = 0;
         if (y >= R && y < h - R && x >= R && x < w - R) {
-            float cand = cand_inner[ly * MTX + lx];
-            int votes = votes_both[ly * MTX + lx] >> 16;
+            const unsigned *col0 = s + ly * TW + lx;
+            const unsigned top = summary[ly * MTX + lx] >> 8;
+            unsigned cand = col0[top & 15u], votes = top >> 4;
 #pragma unroll
-            for (int dy = 1; dy < WS - 1; ++dy)
-                vote_merge(cand_full[(ly + dy) * MTX + lx], votes_both[(ly + dy) * MTX + lx] & 0xffff,
-                           cand, votes);
-            vote_merge(cand_inner[(ly + WS - 1) * MTX + lx], votes_both[(ly + WS - 1) * MTX + lx] >> 16,
-                       cand, votes);
-            if (votes >= 2 * need - CELLS) {
-                const float *win = s + ly * TW + lx;
+            for (int dy = 1; dy < WS - 1; ++dy) {
+                const unsigned p = summary[(ly + dy) * MTX + lx];
+                vote_merge(col0[dy * TW + (p & 15u)], (p >> 4) & 15u, cand, votes);
+            }
+            const unsigned bottom = summary[(ly + WS - 1) * MTX + lx] >> 8;
+            vote_merge(col0[(WS - 1) * TW + (bottom & 15u)], bottom >> 4, cand, votes);
+            if (cand == NAN_KEY) {
+                // no value has the share
+            } else if ((int)votes >= need) {
+                result = cand;                      // the summary holds `votes` copies of it
+            } else if ((int)votes >= 2 * need - CELLS) {
                 int count = 0;
 #pragma unroll
                 for (int dy = 0; dy < WS; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < WS; ++dx) {
                         if ((dy == 0 || dy == WS - 1) && (dx == 0 || dx == WS - 1)) continue;
-                        count += win[dy * TW + dx] == cand;
+                        count += col0[dy * TW + dx] == cand;
                     }
                 if (count >= need) result = cand;
             }
         }
-        out[(size_t)y * w + x] = result;
+        out[(size_t)y * w + x] = __uint_as_float(result);
     }
 }
 
@@ -300,8 +349,8 @@ __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict_
                                                         uint8_t *__restrict__ positive)
 {
     static_assert(FTW == 64 && FTX + 2 * FREACH == FTW, "one wave lane per tile column");
-    __shared__ float ti[FTH * FTW], rowmax[FTH * FTW];
-    __shared__ rowbits nz[FTH], eroded[FTH], expanded[FTH];
+    __shared__ float ti[FTH * FTW];
+    __shared__ rowbits nz[FTH], eroded[FTH], expanded[FTH], nans[FTH];
     const int x0 = blockIdx.x * FTX - FREACH, y0 = blockIdx.y * FTY - FREACH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx = x0 + lane;
@@ -348,19 +397,27 @@ __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict_
         expanded[r] = x;
     }
     __syncthreads();
-    for (int ly = wave; ly < FTH; ly += NT / 64)
-        ti[ly * FTW + lane] *= (expanded[ly] >> lane) & 1 ? 1.0f : 0.0f;
-    __syncthreads();
-    if (lane >= 3 && lane < FTW - 3)
-        for (int ly = 5 + wave; ly < FTH - 5; ly += NT / 64) {
-            float m = -__builtin_inff();
+    // product and row maxima, in place: a tile row belongs to one wave, whose LDS
+    // operations run in order, so its 7 reads are done before its write; a NaN is never
+    // "greater" and only survives at the centre, which nans[] remembers
+    for (int ly = wave; ly < FTH; ly += NT / 64) {
+        float *row = ti + ly * FTW;
+        const float p = row[lane] * ((expanded[ly] >> lane) & 1 ? 1.0f : 0.0f);
+        row[lane] = p;
+        const rowbits isnan = __ballot(p != p);
+        if (lane == 0) nans[ly] = isnan;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float m = -__builtin_inff();
 #pragma unroll
-            for (int dx = -3; dx <= 3; ++dx) {
-                const float v = ti[ly * FTW + lane + dx];
-                m = v > m ? v : m;
-            }
-            rowmax[ly * FTW + lane] = m;
+        for (int dx = -3; dx <= 3; ++dx) {
+            const float v = row[min(max(lane + dx, 0), FTW - 1)];
+            m = v > m ? v : m;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        row[lane] = m;
+    }
     __syncthreads();
     if (lane < FREACH || lane >= FTW - FREACH || gx >= w) return;
     // each wave takes FTY / 4 consecutive rows and keeps the 7 row maxima in registers
@@ -368,15 +425,15 @@ __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict_
     const int first = FREACH + wave * PER;
     float win[7];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) win[k + 1] = rowmax[(first - 3 + k) * FTW + lane];
+    for (int k = 0; k < 6; ++k) win[k + 1] = ti[(first - 3 + k) * FTW + lane];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int ly = first + k, gy = y0 + ly;
 #pragma unroll
         for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
-        win[6] = rowmax[(ly + 3) * FTW + lane];
+        win[6] = ti[(ly + 3) * FTW + lane];
         if (gy >= h) break;
-        float m = ti[ly * FTW + lane];
+        float m = (nans[ly] >> lane) & 1 ? __builtin_nanf("") : -__builtin_inff();
 #pragma unroll
         for (int j = 0; j < 7; ++j) m = win[j] > m ? win[j] : m;
         out[(size_t)gy * w + gx] = m;
