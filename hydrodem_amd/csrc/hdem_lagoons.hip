@@ -22,33 +22,48 @@ inline dim3 grid2(int w, int h) { return dim3((unsigned)((w + NT - 1) / NT), (un
 // its 8 neighbours that are >= 0 (NaN fails the test), summed in float32 the way
 // NumPy's add.reduce does for n <= 8 -- sequentially from 0 below 8 values, as the
 // 8-leaf tree for exactly 8 -- and divided in double (float32 / intp) before the cast.
+__device__ __forceinline__ float correct_nan_cell(const float *__restrict__ in, int h, int w, int y,
+                                                  int x, float v)
+{
+    if (!(v < 0.0f && y >= 1 && y < h - 1 && x >= 1 && x < w - 1)) return v;
+    float a[8];
+    int n = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            const float t = in[(size_t)(y + dy) * w + x + dx];
+            if (t >= 0.0f) a[n++] = t;
+        }
+    float s;
+    if (n == 8) {
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    } else {
+        s = 0.0f;
+        for (int k = 0; k < n; ++k) s += a[k];
+    }
+    return n ? (float)((double)s / (double)n) : __builtin_nanf("");
+}
+
+// 4 cells per lane (unaligned 16-byte accesses); voids are rare, so the neighbour reads
+// of the slow path hardly ever run.
 __global__ __launch_bounds__(NT) void correct_nan_kernel(const float *__restrict__ in, int h, int w,
                                                          float *__restrict__ out)
 {
-    const int x = blockIdx.x * NT + threadIdx.x, y = blockIdx.y;
+    const int x = (blockIdx.x * NT + threadIdx.x) * 4, y = blockIdx.y;
     if (x >= w) return;
-    float v = in[(size_t)y * w + x];
-    if (v < 0.0f && y >= 1 && y < h - 1 && x >= 1 && x < w - 1) {
-        float a[8];
-        int n = 0;
+    const size_t at = (size_t)y * w + x;
+    if (x + 4 <= w) {
+        hdem_f4 v = hdem_ld4u(in + at);
+        if (v[0] < 0.0f || v[1] < 0.0f || v[2] < 0.0f || v[3] < 0.0f) {
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                if (dy == 0 && dx == 0) continue;
-                const float t = in[(size_t)(y + dy) * w + x + dx];
-                if (t >= 0.0f) a[n++] = t;
-            }
-        float s;
-        if (n == 8) {
-            s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        } else {
-            s = 0.0f;
-            for (int k = 0; k < n; ++k) s += a[k];
+            for (int k = 0; k < 4; ++k) v[k] = correct_nan_cell(in, h, w, y, x + k, v[k]);
         }
-        v = n ? (float)((double)s / (double)n) : __builtin_nanf("");
+        hdem_st4u(out + at, v);
+    } else {
+        for (int k = 0; x + k < w; ++k) out[at + k] = correct_nan_cell(in, h, w, y, x + k, in[at + k]);
     }
-    out[(size_t)y * w + x] = v;
 }
 
 // MajorityFilter.apply (:44-73): the value held by more than 70 % of (ws^2 - 1) cells of
@@ -503,8 +518,8 @@ extern "C" int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, 
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     {
         hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)H * W);
-        hipLaunchKernelGGL(correct_nan_kernel, grid2(W, H), dim3(NT), 0, ctx->stream, dem, H, W,
-                           out);
+        hipLaunchKernelGGL(correct_nan_kernel, grid2((W + 3) / 4, H), dim3(NT), 0, ctx->stream, dem,
+                           H, W, out);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
