@@ -1,0 +1,18 @@
+"""Time GrovesCorrectionsIter (3 passes of the 15 x 15 quadratic filter + blend) on an
+n x n raster (exploration).  usage: python tools/groves_time.py [n]"""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hydrodem_amd import backend as B
+import oracle
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+ctx = B.context()
+img = B.DeviceRaster.from_host(oracle.synth_dem(n, n))
+gr = B.DeviceRaster.from_host(oracle.synth_groves(n, n))
+out = B.DeviceRaster.empty((n, n), np.float32)
+scr = B.DeviceRaster.empty((n, n), np.float32)
+for rep in range(12):
+    ctx.synchronize(); t = time.time()
+    B.groves_dev(img, gr, 15, 1.5, 3, out=out, scratch=scr)
+    ctx.synchronize(); dt = time.time() - t
+    print(f"groves x3 {n}^2: {dt*1e3:.2f} ms  ({9*3*n*n/dt/1e9:.0f} GB/s algorithmic)")
