@@ -96,6 +96,26 @@ def test_majority_near_the_share_threshold(window):
         assert 0 < np.count_nonzero(want) < want.size
 
 
+@pytest.mark.parametrize("shape", [(7, 7), (8, 23), (11, 11), (12, 70), (65, 9)])
+def test_smallest_rasters(shape):
+    """Rasters barely larger than the windows (7 for the tidying, 11 for the whole
+    detection): every cell is within reach of a border, the reflected halo of the
+    dilation folds back on itself."""
+    rng = np.random.default_rng([5, *shape])
+    img = np.where(rng.random(shape) < 0.8, 3.0, rng.integers(0, 3, shape)).astype(np.float32)
+    assert np.array_equal(hd.TidyingLagoons().apply(img.copy()), L.tidying_lagoons(img))
+    for ws in (3, 5, 7):
+        assert np.array_equal(hd.MajorityFilter(window_size=ws).apply(img),
+                              L.majority_filter(img, window=ws))
+    if min(shape) >= 11:
+        hs = img.copy()
+        hs[rng.random(shape) < 0.05] = -32768.0
+        want_mask, stages = L.lagoons_detection(hs.copy())
+        det = hd.LagoonsDetection()
+        assert np.array_equal(det.apply(hs.copy()), want_mask)
+        assert np.array_equal(det.lagoons_values, stages["TidyingLagoons"])
+
+
 def test_error_behaviour():
     with pytest.raises(hd.WindowSizeHighError):
         hd.MajorityFilter(window_size=11).apply(np.zeros((8, 30), dtype=np.float32))
