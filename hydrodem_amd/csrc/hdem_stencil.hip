@@ -46,24 +46,37 @@ __device__ __forceinline__ void stage_tile(const T *__restrict__ src, int H, int
     typedef T vec_t __attribute__((ext_vector_type(V)));
     typedef T vecu_t __attribute__((ext_vector_type(V), aligned(sizeof(T))));
     const int tid = threadIdx.x;
-    for (int i = tid; i < (THT + 2) * CPR; i += NT) {
-        int r = i / CPR, c = (i % CPR) * V;
-        int gy = y0 - 1 + r, gx = x0 + c;
-        bool row_ok = gy >= 0 && gy < H;
+    // all of the thread's row chunks are requested before the first one is stored: a
+    // load -> ds_write loop waits out one memory round trip per iteration
+    constexpr int CHUNKS = ((THT + 2) * CPR + NT - 1) / NT;
+    vec_t v[CHUNKS];
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+        const int i = tid + j * NT;
+        const int r = i / CPR, c = (i % CPR) * V;
+        int gy = y0 - 1 + r;
+        const int gx = x0 + c;
+        const bool row_ok = gy >= 0 && gy < H;
         if (REFLECT) gy = reflect(gy, H);
-        vec_t v;
-        if ((row_ok || REFLECT) && gx + V <= W) {
-            v = *reinterpret_cast<const vecu_t *>(src + (size_t)gy * W + gx);
+        if (i >= (THT + 2) * CPR) {
+            v[j] = vec_t(T(0));
+        } else if ((row_ok || REFLECT) && gx + V <= W) {
+            v[j] = *reinterpret_cast<const vecu_t *>(src + (size_t)gy * W + gx);
         } else {
             for (int k = 0; k < V; ++k) {
                 int xx = gx + k;
                 T e = T(0);
                 if (REFLECT) e = src[(size_t)gy * W + reflect(xx, W)];
                 else if (row_ok && xx < W) e = src[(size_t)gy * W + xx];
-                v[k] = e;
+                v[j][k] = e;
             }
         }
-        *reinterpret_cast<vec_t *>(t + r * LS + 4 + c) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+        const int i = tid + j * NT;
+        if (i < (THT + 2) * CPR)
+            *reinterpret_cast<vec_t *>(t + (i / CPR) * LS + 4 + (i % CPR) * V) = v[j];
     }
     for (int i = tid; i < (THT + 2) * 2; i += NT) {
         int r = i >> 1, side = i & 1;
