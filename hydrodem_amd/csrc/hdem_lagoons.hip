@@ -297,9 +297,25 @@ __global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restri
     const int ry = sy / 2, rx = sx / 2, tw = GTX + 2 * rx, th = GTY + 2 * ry;
     float *rowmax = tile + tw * th;                 // th x GTX
     const int x0 = blockIdx.x * GTX, y0 = blockIdx.y * GTY;
-    for (int k = threadIdx.x; k < tw * th; k += NT) {
-        const int ly = k / tw, lx = k - ly * tw;
-        tile[k] = in[(size_t)reflect(y0 - ry + ly, h) * w + reflect(x0 - rx + lx, w)];
+    if (CSY && CSX) {
+        // compiled-in size: all loads of the thread in flight together (a load -> ds_write
+        // loop waits out one memory round trip per cell: 0.78 against 0.50 ms at 16384^2)
+        constexpr int CELLS = (GTX + (CSX ? CSX : 1) - 1) * (GTY + (CSY ? CSY : 1) - 1);
+        constexpr int LOADS = (CELLS + NT - 1) / NT;
+        float v[LOADS];
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j) {
+            const int k = min((int)threadIdx.x + j * NT, CELLS - 1), ly = k / tw, lx = k - ly * tw;
+            v[j] = in[(size_t)reflect(y0 - ry + ly, h) * w + reflect(x0 - rx + lx, w)];
+        }
+#pragma unroll
+        for (int j = 0; j < LOADS; ++j)
+            if ((int)threadIdx.x + j * NT < CELLS) tile[threadIdx.x + j * NT] = v[j];
+    } else {
+        for (int k = threadIdx.x; k < tw * th; k += NT) {
+            const int ly = k / tw, lx = k - ly * tw;
+            tile[k] = in[(size_t)reflect(y0 - ry + ly, h) * w + reflect(x0 - rx + lx, w)];
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x % GTX;
