@@ -41,8 +41,8 @@ FILL_BYTES_PER_CELL = 12    # per tile visit: Z in + W in + W out
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--size", type=int, default=16384)
     p.add_argument("--cpu-sample", type=int, default=2048,
                    help="edge of the crop the CPU oracle is timed on (0 = skip)")

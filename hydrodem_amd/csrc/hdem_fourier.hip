@@ -338,9 +338,10 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
                                                            float *__restrict__ q_out,
                                                            uint8_t *found, uint8_t *total)
 {
-    __shared__ double pre[2][HT + 1];      // inclusive prefix of the big column sums (+ P[-1])
-    __shared__ double sml[2][HT];          // small column sums
-    __shared__ double wtot[2][HT / 64];
+    // [buffer][row of the pair]: two rows share a block barrier, two buffers alternate
+    __shared__ double pre[2][2][HT + 1];   // per-wave inclusive prefix of the big column sums
+    __shared__ double sml[2][2][HT];       // small column sums
+    __shared__ double wtot[2][2][HT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x * (HT - 2 * R) - R + tid;          // my column
     const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, h);
@@ -354,7 +355,6 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
     const bool outputs = tid >= R && tid < HT - R && live;
     const int cols_b = min(c + R, w - 1) - max(c - R, 0) + 1;
     const int cols_s = min(c + r, w - 1) - max(c - r, 0) + 1;
-    if (tid == 0) pre[0][0] = pre[1][0] = 0.0;
     // UN rows per trip: their loads (4 sliding-sum rows + the cell itself, per row) are all
     // issued before the first scan, so the block-wide barriers of a row overlap the memory
     // latency of the next ones instead of adding to it.
@@ -371,36 +371,56 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
             cell[u] = (outputs && y < y1) ? col[(size_t)y * w] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
+        for (int u = 0; u < UN; u += 2) {
             const int y = yb + u;
             if (y >= y1) break;                                   // uniform over the block
-            const int buf = u & 1;
-            // inclusive scan of cb over the 256 lanes
-            double p = wave_scan_f64(cb);
-            if (lane == 63) wtot[buf][wave] = p;
-            sml[buf][tid] = cs;
-            __syncthreads();
-            for (int k = 0; k < wave; ++k) p += wtot[buf][k];
-            pre[buf][tid + 1] = p;
+            const int buf = (u >> 1) & 1;
+            // Two rows per block barrier: their column sums are known up front (the loads are
+            // in), so the two scan chains interleave.  Inclusive scan of the sums inside each
+            // wave; the block-wide prefix of column i is that plus the totals of the waves
+            // before i's, added by the reader.
+            const double cb1 = cb + ((double)in_b[u] - (double)out_b[u]);
+            const double cs1 = cs + ((double)in_s[u] - (double)out_s[u]);
+            const double p0 = wave_scan_f64(cb), p1 = wave_scan_f64(cb1);
+            if (lane == 63) { wtot[buf][0][wave] = p0; wtot[buf][1][wave] = p1; }
+            pre[buf][0][tid + 1] = p0;
+            pre[buf][1][tid + 1] = p1;
+            sml[buf][0][tid] = cs;
+            sml[buf][1][tid] = cs1;
             __syncthreads();
             if (outputs) {
-                const double sb = pre[buf][tid + R + 1] - pre[buf][tid - R];
-                double ss = 0.0;
+                const int a = tid + R, b = tid - R - 1;          // window = columns b+1 .. a
+                const int wa = a >> 6, wb = b >> 6;
 #pragma unroll
-                for (int k = -r; k <= r; ++k) ss += sml[buf][tid + k];
-                const int rows_b = min(y + R, h - 1) - max(y - R, 0) + 1;
-                const int rows_s = min(y + r, h - 1) - max(y - r, 0) + 1;
-                const int cnt = rows_b * cols_b - rows_s * cols_s;
-                const size_t o = (size_t)y * w + c;
-                const float v = cell[u];
-                // nanmean of an empty window is NaN and compares false
-                const bool hit = cnt > 0 && (double)v > (double)factor * ((sb - ss) / (double)cnt);
-                if (found) found[o] = hit ? 1 : 0;
-                if (total && hit) total[o] = (uint8_t)(total[o] + 1);
-                if (q_out) q_out[o] = hit ? v * 0.0f : v;
+                for (int v2 = 0; v2 < 2; ++v2) {
+                    const int yy = y + v2;
+                    if (yy >= y1) break;
+                    const double t1 = wtot[buf][v2][0], t2 = t1 + wtot[buf][v2][1],
+                                 t3 = t2 + wtot[buf][v2][2];
+                    const double hi = pre[buf][v2][a + 1] +
+                                      (wa == 0 ? 0.0 : wa == 1 ? t1 : wa == 2 ? t2 : t3);
+                    const double lo = b < 0 ? 0.0
+                                            : pre[buf][v2][b + 1] +
+                                                  (wb == 0 ? 0.0 : wb == 1 ? t1 : wb == 2 ? t2 : t3);
+                    const double sb = hi - lo;
+                    double ss = 0.0;
+#pragma unroll
+                    for (int k = -r; k <= r; ++k) ss += sml[buf][v2][tid + k];
+                    const int rows_b = min(yy + R, h - 1) - max(yy - R, 0) + 1;
+                    const int rows_s = min(yy + r, h - 1) - max(yy - r, 0) + 1;
+                    const int cnt = rows_b * cols_b - rows_s * cols_s;
+                    const size_t o = (size_t)yy * w + c;
+                    const float v = cell[u + v2];
+                    // q > factor * sum / cnt as q * cnt > factor * sum: no float64 division
+                    // per cell (nanmean of an empty window is NaN and compares false: cnt > 0)
+                    const bool hit = cnt > 0 && (double)v * (double)cnt > (double)factor * (sb - ss);
+                    if (found) found[o] = hit ? 1 : 0;
+                    if (total && hit) total[o] = (uint8_t)(total[o] + 1);
+                    if (q_out) q_out[o] = hit ? v * 0.0f : v;
+                }
             }
-            cb += (double)in_b[u] - (double)out_b[u];
-            cs += (double)in_s[u] - (double)out_s[u];
+            cb = cb1 + ((double)in_b[u + 1] - (double)out_b[u + 1]);
+            cs = cs1 + ((double)in_s[u + 1] - (double)out_s[u + 1]);
         }
     }
 }
