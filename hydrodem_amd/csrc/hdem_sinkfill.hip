@@ -19,15 +19,16 @@
 //     of Z and 64 of W, in VGPRs (a wave-level load moves one 256-byte row
 //     piece; all 128 are in flight together).  A north->south scan walks the
 //     rows in registers: w[r] <- med3(z[r], w[r], min3 of row r-1 at lanes
-//     c-1,c,c+1) -- two v_mov_dpp wave shifts, v_min3, v_med3, v_cmp: 5 VALU per
-//     row, no memory.  South->north likewise.  The window is then transposed
+//     c-1,c,c+1) -- two v_min_f32_dpp (the wave shifts ride on the mins) and a
+//     v_med3: 3 VALU per row, no memory.  South->north runs interleaved with it.  The window is then transposed
 //     through a 64 x 65 LDS buffer (conflict-free both ways) so that lane = row,
 //     and the same code scans west->east and east->west.  The four scans cover
 //     all eight neighbours; a Jacobi check (one full T step, a third of the
 //     cost) decides whether another round of scans is needed;
 //   * the wave writes the tile back once (62 rows x 248 B) and wakes only those
 //     of its 8 neighbour tiles that one of its changed edge cells can still
-//     lower (compared against the halo it holds in registers).
+//     lower: a halo cell (as held in registers) above the new edge value AND
+//     above its own terrain.
 //
 // The schedule:
 //   * every tile has a fixed owner workgroup (tile t -> workgroup t % G, slot
@@ -701,8 +702,7 @@ __device__ __attribute__((noinline)) int async_pick(int b, int G, int S, int nti
 }
 
 // Publish a finished visit: release the written tile, wake the neighbours that can
-// use the new edge, retire (or re-queue) the tile.  `key` is the per-lane key of
-// visit_result.
+// use the new edge, retire (or re-queue) the tile.
 __device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int S, int tiles_x,
                                                        int tiles_y, int *state, int *prio,
                                                        int *pend, unsigned long long *stats,
