@@ -98,7 +98,7 @@ def cpu_baseline(z_crop):
 def filter_paths(B, ctx, zd, scratch, S, reps=3):
     """The other operators of the scope table on the same raster, outside the timed
     region (they are not part of the headline metric): warm call, then ``reps`` timed."""
-    import oracle
+    import hdem_synth
     res = {}
 
     def timed(fn):
@@ -111,7 +111,7 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
         ms = (time.perf_counter() - t0) / reps * 1e3
         return {"ms": ms, "Mcells_per_s": S * S / ms / 1e3}
 
-    mask = B.DeviceRaster.from_host(oracle.synth_groves(S, S), ctx=ctx)
+    mask = B.DeviceRaster.from_host(hdem_synth.synth_groves(S, S), ctx=ctx)
     pong = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
     res["groves_x3"] = dict(timed(lambda: B.groves_dev(zd, mask, iterations=3, out=scratch,
                                                        scratch=pong)),
@@ -172,12 +172,12 @@ def main():
         raise SystemExit(f"--gpus {N} needs torch.distributed.run with {N} ranks "
                          f"(WORLD_SIZE={world})")
 
-    import oracle
+    import hdem_synth               # inputs; oracle/ is only touched by cpu_baseline()
     from hydrodem_amd import backend as B
 
     if N == 1:
         ctx = B.context(0)
-        z = oracle.synth_dem(S, S)
+        z = hdem_synth.synth_dem(S, S)
         zd = B.DeviceRaster.from_host(z, ctx=ctx)
         wd = B.DeviceRaster.empty(z.shape, np.float32, ctx)
         dd = B.DeviceRaster.empty(z.shape, np.uint8, ctx)
@@ -207,7 +207,7 @@ def main():
         H = N * S
         ghost = P.ghost_rows(world, H)                  # one tile row of overlap per seam
         g0, g1, top, bottom = P.local_range(rank, world, H, ghost)
-        z = oracle.synth_dem(H, S, row0=g0, rows=g1 - g0)
+        z = hdem_synth.synth_dem(H, S, row0=g0, rows=g1 - g0)
         dev = torch.device("cuda", local_rank)
         zt = torch.from_numpy(z).to(dev)
         wt = torch.empty_like(zt)

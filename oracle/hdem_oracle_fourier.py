@@ -171,13 +171,4 @@ def detect_apply_fourier(dem):
     return out, mask, stages
 
 
-def synth_striped_dem(h, w_, seed=5, stripes=((0.31, 0.07, 1.2), (0.12, 0.38, 0.8))):
-    """Synthetic DEM with a few plane waves of 1 m scale on top (the SRTM striping
-    artefact the destripe removes): each (fy, fx, amplitude), cycles per cell."""
-    from .hdem_oracle_np import synth_dem
-    z = synth_dem(h, w_, pits=False).astype(np.float64)
-    y, x = np.mgrid[0:h, 0:w_]
-    rng = np.random.default_rng([20240607, seed])
-    for fy, fx, amp in stripes:
-        z += amp * np.sin(2 * np.pi * (fy * y + fx * x) + rng.uniform(0, 2 * np.pi))
-    return z.astype(np.float32)
+from hdem_synth import synth_striped_dem  # noqa: E402,F401  (re-exported for the tests)

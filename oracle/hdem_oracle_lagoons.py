@@ -98,19 +98,4 @@ def lagoons_detection(hsheds):
     return mask, {"CorrectNANValues": fixed, "MajorityFilter": major, "TidyingLagoons": tidy}
 
 
-def synth_hsheds(h, w_, seed=11):
-    """HydroSHEDS-like raster: integer-metre terrain, flat lagoons (constant
-    elevation discs), and a few voids coded as large negative numbers."""
-    from .hdem_oracle_np import synth_dem
-    rng = np.random.default_rng([20240607, seed, h, w_])
-    z = np.round(synth_dem(h, w_, pits=False)).astype(np.float32)
-    yy, xx = np.mgrid[0:h, 0:w_]
-    for _ in range(max(2, h * w_ // 6000)):
-        cy, cx = rng.integers(0, h), rng.integers(0, w_)
-        rad = rng.integers(5, 14)
-        disc = (yy - cy) ** 2 + (xx - cx) ** 2 <= rad ** 2
-        z[disc] = z[min(cy, h - 1), min(cx, w_ - 1)]
-    void = rng.random((h, w_)) < 0.004
-    z[void] = -32768.0
-    z[h // 3:h // 3 + 3, w_ // 4:w_ // 4 + 4] = -32768.0        # voids with only void neighbours
-    return z
+from hdem_synth import synth_hsheds  # noqa: E402,F401  (re-exported for the tests)

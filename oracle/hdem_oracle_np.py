@@ -285,62 +285,7 @@ def boxmean3(x):
 
 
 # ---------------------------------------------------------------------------
-# Synthetic DEM generator -- shared by tests and bench so that the
-# GPU run and the CPU baseline see the same cells.  Block-seeded: rows
-# [r0, r1) of an H x W raster are identical whatever partition asks for them.
+# Synthetic rasters: generated by hdem_synth.py (repo root; shared with bench.py, which
+# must not depend on this package for its inputs), re-exported here for the tests.
 # ---------------------------------------------------------------------------
-
-GEN_SEED = 20240607
-GEN_BLOCK = 1024
-
-
-def synth_dem(h, w_, row0=0, rows=None, variant="rough", pits=True,
-              total_rows=None):
-    """Rows [row0, row0+rows) of the synthetic H x W float32 DEM.
-
-    Z = 100 + 0.002 x + 0.001 y + sum_k A_k sin(2 pi (x u_k + y v_k))
-        + 0.5 * N(0,1),  A = 8,4,2,1 m at wavelengths 4096,1024,256,64 cells,
-    plus ~0.1 % single-cell pits (-5 m).  ``variant='srtm'`` rounds to
-    integer metres (large flats and ties, the regime of ``final_dem.tif``).
-    """
-    rows = h - row0 if rows is None else rows
-    out = np.empty((rows, w_), dtype=np.float32)
-    x = np.arange(w_, dtype=np.float64)[None, :]
-    amps = (8.0, 4.0, 2.0, 1.0)
-    lams = (4096.0, 1024.0, 256.0, 64.0)
-    angs = (0.3, 1.1, 2.0, 2.9)
-    r = row0
-    while r < row0 + rows:
-        blk = r // GEN_BLOCK
-        b0 = blk * GEN_BLOCK
-        b1 = min(b0 + GEN_BLOCK, h)
-        rng = np.random.default_rng([GEN_SEED, blk, w_])
-        noise = rng.standard_normal((b1 - b0, w_), dtype=np.float32)
-        pit = rng.random((b1 - b0, w_), dtype=np.float32) < 0.001
-        y = np.arange(b0, b1, dtype=np.float64)[:, None]
-        zz = 100.0 + 0.002 * x + 0.001 * y
-        for a, lam, ang in zip(amps, lams, angs):
-            # sin(px + py) expanded so that only 1-D sines are evaluated
-            px = 2 * np.pi * np.cos(ang) / lam * x
-            py = 2 * np.pi * np.sin(ang) / lam * y
-            zz += a * (np.sin(px) * np.cos(py) + np.cos(px) * np.sin(py))
-        zz += 0.5 * noise
-        if pits:
-            zz = np.where(pit, zz - 5.0, zz)
-        lo = max(r, b0)
-        hi = min(row0 + rows, b1)
-        out[lo - row0:hi - row0] = zz[lo - b0:hi - b0].astype(np.float32)
-        r = hi
-    if variant == "srtm":
-        out = np.round(out).astype(np.float32)
-    return out
-
-
-def synth_groves(h, w_, seed=7):
-    """Bernoulli(0.05) mask closed with a 3x3 structuring element (the
-    reference closes its class raster the same way, image_srtm.py:177-178);
-    uint8 0/1."""
-    from scipy.ndimage import binary_closing
-    rng = np.random.default_rng([GEN_SEED, seed, h, w_])
-    raw = rng.random((h, w_), dtype=np.float32) < 0.05
-    return binary_closing(raw, structure=np.ones((3, 3))).astype(np.uint8)
+from hdem_synth import GEN_BLOCK, GEN_SEED, synth_dem, synth_groves  # noqa: E402,F401

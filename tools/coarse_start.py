@@ -7,11 +7,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HDEM_FILL_TRACE", "1")
 from hydrodem_amd import backend as B, partition as P
-import oracle
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 variant = sys.argv[2] if len(sys.argv) > 2 else "rough"
 solver = P.HipLocalSolver(0)
-z = torch.from_numpy(oracle.synth_dem(n, n, variant=variant)).cuda()
+z = torch.from_numpy(hdem_synth.synth_dem(n, n, variant=variant)).cuda()
 ref = torch.empty_like(z)
 for _ in range(2):
     torch.cuda.synchronize(); t = time.perf_counter(); v = solver.fill(z, ref, 0.0, B.FILL_INIT); torch.cuda.synchronize()

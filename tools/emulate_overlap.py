@@ -7,7 +7,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B, partition as P
-import oracle
+import hdem_synth
 
 N, S, W, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 H, BLK = N * S, 16
@@ -15,7 +15,7 @@ blocks = []
 for r in range(N):
     r0, r1 = r * S, (r + 1) * S
     lo, hi = max(r0 - G, 0), min(r1 + G, H)
-    zt = torch.from_numpy(oracle.synth_dem(H, W, row0=lo, rows=hi - lo)).cuda()
+    zt = torch.from_numpy(hdem_synth.synth_dem(H, W, row0=lo, rows=hi - lo)).cuda()
     blocks.append({"z": zt, "w": torch.empty_like(zt), "lo": lo, "hi": hi, "r0": r0, "r1": r1,
                    "top": r > 0, "bot": r < N - 1, "solver": P.HipLocalSolver(0, own_context=True)})
 # global coarse raster (every rank's owned rows, stacked) and per-block row maps

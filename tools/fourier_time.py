@@ -4,11 +4,11 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B
-from oracle import hdem_oracle_fourier as F
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = B.context()
-dem = F.synth_striped_dem(n, n)
+dem = hdem_synth.synth_striped_dem(n, n)
 d = B.DeviceRaster.from_host(dem); out = B.DeviceRaster.empty(dem.shape, np.float32)
 names = {B.K_FFT: "rocFFT c2c", B.K_FOURIER_DETECT: "detect",
          B.K_FOURIER_MASK: "mask kernels", B.K_FOURIER_POINT: "pointwise"}

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B, partition as P
-import oracle
+import hdem_synth
 
 N = int(sys.argv[1]); S = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
@@ -15,7 +15,7 @@ H = N * S
 blocks = []
 for r in range(N):
     g0, g1, top, bot = P.local_range(r, N, H)
-    zt = torch.from_numpy(oracle.synth_dem(H, W, row0=g0, rows=g1 - g0)).cuda()
+    zt = torch.from_numpy(hdem_synth.synth_dem(H, W, row0=g0, rows=g1 - g0)).cuda()
     blocks.append({"z": zt, "w": torch.empty_like(zt), "top": top, "bot": bot,
                    "solver": P.HipLocalSolver(0, own_context=True)})
 def fill(b, flags, z=None, w=None):

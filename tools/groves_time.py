@@ -4,11 +4,11 @@ import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B
-import oracle
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = B.context()
-img = B.DeviceRaster.from_host(oracle.synth_dem(n, n))
-gr = B.DeviceRaster.from_host(oracle.synth_groves(n, n))
+img = B.DeviceRaster.from_host(hdem_synth.synth_dem(n, n))
+gr = B.DeviceRaster.from_host(hdem_synth.synth_groves(n, n))
 out = B.DeviceRaster.empty((n, n), np.float32)
 scr = B.DeviceRaster.empty((n, n), np.float32)
 for rep in range(12):

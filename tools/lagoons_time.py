@@ -4,10 +4,10 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B
-import oracle
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = B.context()
-hs = np.round(oracle.synth_dem(n, n)); hs[::97, ::89] = -32768.0
+hs = np.round(hdem_synth.synth_dem(n, n)); hs[::97, ::89] = -32768.0
 d = B.DeviceRaster.from_host(hs)
 for rep in range(3):
     ctx.profile(True); ctx.profile_reset()

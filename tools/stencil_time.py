@@ -4,10 +4,10 @@ import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B
-import oracle
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = B.context()
-z = B.DeviceRaster.from_host(oracle.synth_dem(n, n))
+z = B.DeviceRaster.from_host(hdem_synth.synth_dem(n, n))
 codes = B.DeviceRaster.empty((n, n), np.uint8)
 out = B.DeviceRaster.empty((n, n), np.float32)
 def timed(f, reps=10):

@@ -4,10 +4,10 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B, streaming as S
-import oracle
+import hdem_synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 band = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-img, mask = oracle.synth_dem(n, n, pits=False), oracle.synth_groves(n, n)
+img, mask = hdem_synth.synth_dem(n, n, pits=False), hdem_synth.synth_groves(n, n)
 for rep in range(2):
     t = time.time(); a = B.groves(img, mask, iterations=3); dt = time.time() - t
     print(f"whole-array host call: {dt*1e3:.1f} ms -> {n*n/dt/1e6:.0f} Mcells/s")
