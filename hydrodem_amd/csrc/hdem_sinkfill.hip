@@ -57,6 +57,7 @@ constexpr int TS = WN + 1;         // LDS row stride (floats): conflict-free tra
 constexpr int NT = 64;             // one wave per workgroup
 constexpr int ITER_MAX = 8;        // 4-scan iterations before the tile re-queues
 constexpr int INIT_NT = 256;
+constexpr int INIT_ROWS = 4;        // output rows per lane of fill_init_kernel
 constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
 constexpr int SEED_KEYS = 1 << 20;     // queue keys below this: seeds (flood order)
 constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (agent scope)
@@ -811,24 +812,18 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
                                                       int shift,
                                                       const int *__restrict__ row_map)
 {
+    // A lane makes 4 columns x INIT_ROWS rows: INIT_ROWS + 2 rows of loads (all in flight
+    // together) instead of 3 per output row.
     const int quads = (W + 3) / 4;
     const size_t q = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
-    if (q >= (size_t)H * quads) return;
-    const int y = (int)(q / quads), x = (int)(q % quads) * 4;
-    // start value of the free cells: +inf, or the filled level of the cell's block in a
-    // coarse (block maximum) raster -- an upper bound of the fill (hdem_coarsen.hip); the
-    // 4 cells of a lane share a block (blocks are >= 4 wide, x is a multiple of 4)
-    float level = HDEM_INF;
-    if (coarse) {
-        level = coarse[(size_t)(row_map ? row_map[y] : (y >> shift)) * cw + (x >> shift)];
-        if (level >= 3.0e38f) level = HDEM_INF;            // a nodata wall stays a wall
-    }
-    // rows y-1, y, y+1, columns x-1 .. x+4 (clamped: a clamped duplicate cannot add a NaN
-    // that is not already in the neighbourhood)
-    float v[3][6];
+    if (q >= (size_t)((H + INIT_ROWS - 1) / INIT_ROWS) * quads) return;
+    const int y0 = (int)(q / quads) * INIT_ROWS, x = (int)(q % quads) * 4;
+    // rows y0-1 .. y0+INIT_ROWS, columns x-1 .. x+4 (clamped: a clamped duplicate cannot
+    // add a NaN that is not already in the neighbourhood)
+    float v[INIT_ROWS + 2][6];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float *row = z + (size_t)min(max(y + r - 1, 0), H - 1) * W;
+    for (int r = 0; r < INIT_ROWS + 2; ++r) {
+        const float *row = z + (size_t)min(max(y0 + r - 1, 0), H - 1) * W;
         v[r][0] = row[max(x - 1, 0)];
         if (x + 4 <= W) {
             const hdem_f4 m = hdem_ld4u(row + x);
@@ -839,48 +834,61 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
         }
         v[r][5] = row[min(x + 4, W - 1)];
     }
-    float o[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int xx = x + k;
-        const float zc = v[1][1 + k];
-        // a ghost row belongs to the neighbouring row block: only its two border
-        // cells are pinned; the rest waits at +inf for the first halo exchange
-        const bool ghost = ((ghost_top && y == 0) || (ghost_bottom && y == H - 1)) &&
-                           xx != 0 && xx != W - 1;
-        bool pin = y == 0 || y == H - 1 || xx == 0 || xx >= W - 1 || zc != zc;
+    for (int rr = 0; rr < INIT_ROWS; ++rr) {
+        const int y = y0 + rr;
+        if (y >= H) break;
+        // start value of the free cells: +inf, or the filled level of the cell's block in a
+        // coarse (block maximum) raster -- an upper bound of the fill (hdem_coarsen.hip); the
+        // 4 cells of a lane share a block (blocks are >= 4 wide, x is a multiple of 4)
+        float level = HDEM_INF;
+        if (coarse) {
+            level = coarse[(size_t)(row_map ? row_map[y] : (y >> shift)) * cw + (x >> shift)];
+            if (level >= 3.0e38f) level = HDEM_INF;            // a nodata wall stays a wall
+        }
+        float o[4];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x + k;
+            const float zc = v[rr + 1][1 + k];
+            // a ghost row belongs to the neighbouring row block: only its two border
+            // cells are pinned; the rest waits at +inf for the first halo exchange
+            const bool ghost = ((ghost_top && y == 0) || (ghost_bottom && y == H - 1)) &&
+                               xx != 0 && xx != W - 1;
+            bool pin = y == 0 || y == H - 1 || xx == 0 || xx >= W - 1 || zc != zc;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pin |= v[r][k + c] != v[r][k + c];
-        if (ghost && ghost_given) {
-            // the caller's upper bound: acts like a pinned cell until the first exchange
-            // (never below the terrain, whatever the caller wrote)
-            const float g = xx < W ? w[(size_t)y * W + xx] : zc;
-            o[k] = zc != zc ? zc : fmaxf(g, zc);
-            if (zc == zc && g == g && tiles_x > 0 && xx < W) {
-                const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
-                atomicMin(&tile_key[ty * tiles_x + tx], float_key(o[k]));
-            }
-        } else if (ghost) {
-            o[k] = zc != zc ? zc : fmaxf(level, zc);
-        } else {
-            o[k] = pin ? zc : fmaxf(level, zc);
-            if (pin && zc == zc && tiles_x > 0 && xx < W) {
-                // the tile whose interior is nearest (ring cells belong to no interior)
-                const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
-                atomicMin(&tile_key[ty * tiles_x + tx], float_key(zc));
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pin |= v[rr + r][k + c] != v[rr + r][k + c];
+            if (ghost && ghost_given) {
+                // the caller's upper bound: acts like a pinned cell until the first exchange
+                // (never below the terrain, whatever the caller wrote)
+                const float g = xx < W ? w[(size_t)y * W + xx] : zc;
+                o[k] = zc != zc ? zc : fmaxf(g, zc);
+                if (zc == zc && g == g && tiles_x > 0 && xx < W) {
+                    const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
+                    atomicMin(&tile_key[ty * tiles_x + tx], float_key(o[k]));
+                }
+            } else if (ghost) {
+                o[k] = zc != zc ? zc : fmaxf(level, zc);
+            } else {
+                o[k] = pin ? zc : fmaxf(level, zc);
+                if (pin && zc == zc && tiles_x > 0 && xx < W) {
+                    // the tile whose interior is nearest (ring cells belong to no interior)
+                    const int ty = min(max(y - 1, 0), H - 3) / FT, tx = min(max(xx - 1, 0), W - 3) / FT;
+                    atomicMin(&tile_key[ty * tiles_x + tx], float_key(zc));
+                }
             }
         }
-    }
-    float *dst = w + (size_t)y * W + x;
-    if (x + 4 <= W) {
-        const hdem_f4 m = {o[0], o[1], o[2], o[3]};
-        hdem_st4u(dst, m);
-    } else {
+        float *dst = w + (size_t)y * W + x;
+        if (x + 4 <= W) {
+            const hdem_f4 m = {o[0], o[1], o[2], o[3]};
+            hdem_st4u(dst, m);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (x + k < W) dst[k] = o[k];
+            for (int k = 0; k < 4; ++k)
+                if (x + k < W) dst[k] = o[k];
+        }
     }
 }
 
@@ -1101,7 +1109,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
 
     if (!warm) {
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
-        const size_t n = (size_t)H * ((W + 3) / 4);
+        const size_t n = (size_t)((H + INIT_ROWS - 1) / INIT_ROWS) * ((W + 3) / 4);
         hipLaunchKernelGGL(fill_init_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
                            dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
                            flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM,
