@@ -87,6 +87,9 @@ void hdem_fourier_release(hdem_ctx *ctx);
 // A device buffer of at least `bytes` that stays with the context (one user at a time:
 // the chains carve it up themselves).  nullptr + error set on failure.
 void *hdem_arena(hdem_ctx *ctx, size_t bytes);
+// hdem_stencil.hip: streaming certification of a filled surface (+ its D8 codes)
+int hdem_certify_d8_launch(hdem_ctx *ctx, const float *z, const float *w, int H, int W, float eps,
+                           uint8_t *d8, int *flag);
 
 static inline int hdem_check_raster(const void *in, const void *out, int H,
                                     int W)

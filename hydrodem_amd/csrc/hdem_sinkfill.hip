@@ -1128,21 +1128,27 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         // wall-clock budget (100 MHz ticks): generous against the ~0.15 us per tile a
         // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second;
         // or the caller's time slice (soft: the launch just stops taking tiles)
-        const long long budget = slice_us > 0 ? (long long)slice_us * 100ll
-                                              : 20000000ll + (long long)ws.ntiles * 200ll;
+        long long budget = slice_us > 0 ? (long long)slice_us * 100ll
+                                        : 20000000ll + (long long)ws.ntiles * 200ll;
+        int soft = slice_us > 0;
+        // (tests: cut the asynchronous phase short so that the passes behind it have work)
+        if (const char *tb = getenv("HDEM_FILL_TEST_BUDGET_US")) {
+            budget = atoll(tb) * 100ll;
+            soft = 1;
+        }
         hdem_scoped_timer tm(ctx, async_id, 0);
         if (eps != 0.0f)
             hipLaunchKernelGGL((fill_async_kernel<true, 0>), dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
         else if (ctx->in_coarse_presolve)
             hipLaunchKernelGGL((fill_async_kernel<false, 1>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
         else
             hipLaunchKernelGGL((fill_async_kernel<false, 0>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, slice_us > 0);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
@@ -1176,7 +1182,23 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // (the pass must see every tile: behind the asynchronous phase, or a WARM round-driver
     // call with all tiles due -- the verifying call of the row-block loop)
     if (!(verify && (did_async || (warm && mode == 0)))) d8 = nullptr;
-    if (ws.ntiles > 0 && verify)
+    // Behind the asynchronous phase -- and in the verifying call of the row-block loop --
+    // the surface is normally final: certify it with one streaming pass (hdem_stencil.hip;
+    // it also writes the flow directions) and only fall back to certifying rounds of tile
+    // visits when that pass finds a cell to lower.
+    // (HDEM_FILL_CERTIFY_ROUNDS: always the rounds.)
+    const bool sees_all = did_async || (warm && mode == 0);      // (as for d8 above)
+    if (ws.ntiles > 0 && verify && sees_all && !getenv("HDEM_FILL_CERTIFY_ROUNDS")) {
+        int *flag = ws.any + max_rounds + 16;              // zeroed with any[]
+        {
+            hdem_scoped_timer tm(ctx, HDEM_K_FILL_ROUND, (int64_t)H * W);
+            if (int rc = hdem_certify_d8_launch(ctx, z, w, H, W, eps, d8, flag)) return rc;
+        }
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HDEM_HIP_CHECK(hipStreamSynchronize(st));
+        if (ctx->host_counts[0] == 0) converged = 1;
+    }
+    if (ws.ntiles > 0 && verify && !converged)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
                            ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any, nullptr, 0,

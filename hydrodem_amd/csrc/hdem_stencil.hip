@@ -169,6 +169,87 @@ __global__ __launch_bounds__(NT) void d8_kernel(const float *__restrict__ z, int
 }
 
 // ---------------------------------------------------------------------------
+// Certifying pass of the sink fill as a stream (hdem_sinkfill.hip runs it behind the
+// asynchronous phase): W is at the fixed point iff no interior cell can be lowered,
+//     med3(z, w, min over the 3 x 3 window of w (+ eps)) == w      (NaN = the wall +inf),
+// the test the tile visit's check_rows makes, here without tiles or a worklist: the
+// d8_kernel shape (W staged in LDS, three rolling rows), one 16-byte load of Z per lane
+// and row on top, and the flow directions of the certified surface on request.  *flag
+// is set when some cell could still be lowered; the caller then falls back to the round
+// driver.  9 B/cell with directions, 8 without.
+// ---------------------------------------------------------------------------
+template <bool HAS_EPS>
+__global__ __launch_bounds__(NT) void certify_d8_kernel(const float *__restrict__ z,
+                                                       const float *__restrict__ w, int H, int W,
+                                                       float eps, uint8_t *__restrict__ out,
+                                                       int tiles_x, int vec_store, int *flag)
+{
+    __shared__ __attribute__((aligned(16))) float t[(TH + 2) * LS];
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int x0 = bx * TW, y0 = by * TH;
+    stage_tile<float, false>(w, H, W, y0, x0, t);
+    __syncthreads();
+
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int x = x0 + 4 * cg;
+    if (x >= W) return;
+    // the lane's Z: 8 rows x 4 cells, requested before the first is used
+    float zc[8][4];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int y = min(y0 + rg * 8 + rr, H - 1);
+        if (x + 4 <= W) {
+            const hdem_f4 m = hdem_ld4u(z + (size_t)y * W + x);
+            zc[rr][0] = m[0]; zc[rr][1] = m[1]; zc[rr][2] = m[2]; zc[rr][3] = m[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zc[rr][k] = z[(size_t)y * W + min(x + k, W - 1)];
+        }
+    }
+    bool lower = false;
+    float a[6], b[6], c[6];
+    read_row6(t, rg * 8 + 0, cg, a);
+    read_row6(t, rg * 8 + 1, cg, b);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int y = y0 + rg * 8 + rr;
+        read_row6(t, rg * 8 + rr + 2, cg, c);
+        if (y < H) {
+            unsigned code[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x + k;
+                const bool interior = y > 0 && y < H - 1 && xx > 0 && xx < W - 1;
+                // fminf skips a NaN operand: nodata neighbours are walls
+                float m = fminf(fminf(fminf(a[k], a[k + 1]), fminf(a[k + 2], b[k])),
+                                fminf(fminf(b[k + 1], b[k + 2]), fminf(c[k], fminf(c[k + 1], c[k + 2]))));
+                m = fminf(m, HDEM_INF);
+                if (HAS_EPS) m += eps;
+                const float wc = fminf(b[k + 1], HDEM_INF), zz = fminf(zc[rr][k], HDEM_INF);
+                lower |= interior && __builtin_amdgcn_fmed3f(zz, wc, m) != wc;
+                const unsigned cd = d8_code(a[k], a[k + 1], a[k + 2], b[k], b[k + 1], b[k + 2], c[k],
+                                            c[k + 1], c[k + 2]);
+                code[k] = interior ? cd : 0u;
+            }
+            if (out) {
+                uint8_t *o = out + (size_t)y * W + x;
+                if (vec_store && x + 4 <= W) {
+                    *reinterpret_cast<uint32_t *>(o) =
+                        code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) o[k] = (uint8_t)code[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a[k] = b[k]; b[k] = c[k]; }
+    }
+    if (lower) *flag = 1;                           // (every writer stores the same value)
+}
+
+// ---------------------------------------------------------------------------
 // A5  3x3 box mean (+ round).  Reference arithmetic: SciPy accumulates the
 // nine window values in double in raster order starting from 0, casts the sum
 // to the array dtype; the filter divides by 9 in that dtype
@@ -280,6 +361,24 @@ inline int tiles_of(int H, int W, int th, int *tx)
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+// (internal: hdem_sinkfill.hip) one streaming certification of W against Z, with the D8
+// codes of W when d8 != NULL; *flag (device, zeroed by the caller) != 0 afterwards: not a
+// fixed point yet
+int hdem_certify_d8_launch(hdem_ctx *ctx, const float *z, const float *w, int H, int W, float eps,
+                           uint8_t *d8, int *flag)
+{
+    int tx, nt = tiles_of(H, W, TH, &tx);
+    const int vec = d8 && (W % 4 == 0) && ((uintptr_t)d8 % 4 == 0);
+    if (eps != 0.0f)
+        hipLaunchKernelGGL(certify_d8_kernel<true>, dim3(nt), dim3(NT), 0, ctx->stream, z, w, H, W,
+                           eps, d8, tx, vec, flag);
+    else
+        hipLaunchKernelGGL(certify_d8_kernel<false>, dim3(nt), dim3(NT), 0, ctx->stream, z, w, H, W,
+                           eps, d8, tx, vec, flag);
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
 extern "C" int hdem_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, uint8_t *out)
 {
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");

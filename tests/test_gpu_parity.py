@@ -108,6 +108,34 @@ def test_sinkfill_round_driver_alone():
     assert st2["rounds"] <= 3
 
 
+def test_sinkfill_certification_paths(monkeypatch):
+    """Behind the asynchronous phase one streaming pass certifies the surface (and writes
+    the flow directions).  When it finds a cell that can still be lowered -- here: the
+    asynchronous phase is cut short -- the rounds of tile visits take over; and the rounds
+    alone (HDEM_FILL_CERTIFY_ROUNDS) must agree as well."""
+    z = oracle.synth_dem(1500, 1300)
+    z[700:720, 100:130] = np.nan                                  # a nodata block
+    want = c_oracle.sinkfill_pflood(z)
+    want_d8 = c_oracle.d8(want)
+    for env, value in ((None, None), ("HDEM_FILL_TEST_BUDGET_US", "150"),
+                       ("HDEM_FILL_CERTIFY_ROUNDS", "1")):
+        if env:
+            monkeypatch.setenv(env, value)
+        with backend.DeviceRaster.from_host(z) as zd:
+            out, codes, st = backend.sinkfill_d8_dev(zd)
+            got, got_d8 = out.to_host(), codes.to_host()
+            out.free()
+            codes.free()
+        if env:
+            monkeypatch.delenv(env)
+        assert st["converged"] == 1
+        assert np.array_equal(got, want, equal_nan=True) and np.array_equal(got_d8, want_d8)
+        if env is None:
+            assert st["rounds"] == 0 and st["round_visits"] == 0     # the stream certified
+        else:
+            assert st["rounds"] >= 1 and st["round_visits"] > 0       # tile visits did
+
+
 def test_sinkfill_matches_jacobi_definition():
     z = oracle.synth_dem(96, 140)
     want, _ = oracle.sinkfill_jacobi(z)
