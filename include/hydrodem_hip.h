@@ -78,7 +78,7 @@ typedef enum hdem_kernel_id {
     HDEM_K_GROVES = 4,        /* fused quadratic + groves epilogue          */
     HDEM_K_CONVOLVE = 5,
     HDEM_K_FILL_SCAN = 6,     /* (reserved)                                 */
-    HDEM_K_FILL_ROUND = 7,    /* round-synchronous certifying / finishing pass */
+    HDEM_K_FILL_ROUND = 7,    /* certifying stream + finishing rounds of tile visits */
     HDEM_K_BLOCKMAX = 8,      /* block-maximum coarsening (multi-GPU start values) */
     HDEM_K_FFT = 9,           /* rocFFT 2-D complex transform (forward or inverse) */
     HDEM_K_FOURIER_ROWSUM = 10, /* hollow mean, row pass                       */
@@ -109,8 +109,9 @@ int hdem_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, uint8_t *out);
 
 /* ---- A1  SinkFill.apply  (new operator; no reference body -- SURVEY F2) -- */
 typedef struct hdem_fill_stats {
-    int32_t rounds;           /* round-synchronous launches that had work      */
-    int32_t converged;        /* 1 when a round found nothing left to do       */
+    int32_t rounds;           /* round-synchronous launches that had work (0: the
+                                 certifying stream found the surface final)     */
+    int32_t converged;        /* 1: certified fixed point                      */
     int64_t tile_visits;      /* tile visits, both drivers                     */
     int64_t tiles;            /* tiles in the raster                         */
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
@@ -134,7 +135,7 @@ typedef struct hdem_fill_stats {
                                    /* exchange replaced ghost row 0 / H-1)                */
 #define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
 #define HDEM_FILL_SYNC_ONLY   0x40 /* skip the asynchronous phase (round-synchronous only) */
-#define HDEM_FILL_NO_VERIFY   0x80 /* skip the certifying round pass behind the asynchronous
+#define HDEM_FILL_NO_VERIFY   0x80 /* skip the certifying pass behind the asynchronous
                                       phase: for intermediate solves of a halo-exchange loop
                                       whose last solve is a verifying one                  */
 #define HDEM_FILL_RESUME      0x100 /* WARM: keep the worklist the previous call on this context
@@ -161,10 +162,10 @@ int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W,
                           float eps, int max_rounds, int flags, float *w,
                           hdem_fill_stats *stats);
 /* Sink fill and D8 of the filled surface in one call (what HydroConditioning and the
- * headline benchmark run).  The certifying pass of the fill holds every tile's final
- * surface in registers; with this entry point it writes the flow directions from there
- * instead of a second pass over w (same codes as hdem_d8_f32_dev, bit for bit; falls back
- * to that kernel when the call has no certifying pass over every tile). */
+ * headline benchmark run).  The certifying pass of the fill streams over Z and W once;
+ * with this entry point it writes the flow directions on the way instead of a second pass
+ * over w (same codes as hdem_d8_f32_dev, bit for bit; falls back to that kernel when the
+ * call has no certifying pass over the whole raster). */
 int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float eps,
                              int max_rounds, int flags, float *w, uint8_t *d8,
                              hdem_fill_stats *stats);
