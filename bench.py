@@ -139,8 +139,17 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
                       ("pointwise", B.K_FOURIER_POINT)):
         res["fourier_destripe"][name + "_ms"] = ctx.profile_get(kid)["ms"] / n_calls
     ctx.profile(False)
-    # lagoon branch (SURVEY 8f-3) on the integer-metre variant of the raster with voids
+    # SURVEY 8d's second input variant: the same DEM in integer metres (large flats, ties)
     hs = np.round(zd.to_host())
+    hd_ = B.DeviceRaster.from_host(hs, ctx=ctx)
+    codes = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
+    info = {}
+    res["sinkfill_d8_srtm_variant"] = timed(
+        lambda: info.update(B.sinkfill_d8_dev(hd_, out=scratch, codes=codes)[2]))
+    res["sinkfill_d8_srtm_variant"]["tile_visits"] = info.get("tile_visits")
+    codes.free()
+    hd_.free()
+    # lagoon branch (SURVEY 8f-3) on the integer-metre variant of the raster with voids
     hs[::97, ::89] = -32768.0
     hd_ = B.DeviceRaster.from_host(hs, ctx=ctx)
     del hs
