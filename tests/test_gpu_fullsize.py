@@ -90,6 +90,21 @@ def test_destripe_full_size_properties():
     assert abs(out.mean(dtype=np.float64) - dem.mean(dtype=np.float64)) < 1e-3
 
 
+def test_sinkfill_and_d8_at_the_column_count_of_the_largest_config(built):
+    """BASELINE config 5 cuts 65536 x 65536 into row blocks of 8192 x 65536: the width
+    (row stride, tile columns, 32-bit offsets inside a window) at full size, on a band
+    that the C oracle still fills in seconds."""
+    h, w = 700, 65536 + 37
+    z = oracle.synth_dem(h, w)
+    wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z))
+    want = c_oracle.sinkfill_pflood(z)
+    assert st["converged"] == 1
+    assert np.array_equal(wd.to_host(), want)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    wd.free()
+    codes.free()
+
+
 def test_lagoons_full_size_on_crops():
     """LagoonsDetection at 16384^2 against the oracle on crops: the chain is local
     (reach 1 + 5 + 8 cells), so a crop reproduces every cell further than that from
