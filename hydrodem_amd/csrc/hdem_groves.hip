@@ -298,12 +298,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 const f2 r = {r0[2 * p2], r0[2 * p2 + 1]}, t = {r2[2 * p2], r2[2 * p2 + 1]};
+                // (all the adds, then all the fmas: written as add-then-fma per slot the
+                // compiler reuses one temporary, and a packed fma that consumes the packed
+                // add just before it needs a wait state -- 30 s_nop per row)
+#pragma unroll
+                for (int j = 0; j < WS; ++j) acc[j][p2] += t;
 #pragma unroll
                 for (int j = 0; j < WS; ++j) {
                     // output row (i - j) sits in slot (u - j) mod WS and takes weight cy[j]
                     const int sl = ((u - j) % WS + WS) % WS;
                     const f2 cy = {cf.cy[j], cf.cy[j]};
-                    acc[sl][p2] = __builtin_elementwise_fma(cy, r, acc[sl][p2] + t);
+                    acc[sl][p2] = __builtin_elementwise_fma(cy, r, acc[sl][p2]);
                 }
             }
             // ---- output row i - 2p is complete: blend and store ------------------------
