@@ -336,7 +336,10 @@ template <int R, int r>
 __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restrict__ q, int h, int w,
                                                            float factor, int seg,
                                                            float *__restrict__ q_out,
-                                                           uint8_t *found, uint8_t *total)
+                                                           uint8_t *found, uint8_t *total,
+                                                           uint8_t *occ_mark,
+                                                           const uint8_t *__restrict__ occ_skip,
+                                                           int occ_w)
 {
     // [buffer][row of the pair]: two rows share a block barrier, two buffers alternate
     __shared__ double pre[2][2][HT + 1];   // per-wave inclusive prefix of the big column sums
@@ -345,6 +348,20 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x * (HT - 2 * R) - R + tid;          // my column
     const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, h);
+    if (occ_skip) {
+        // Second pass: a cell can only become a peak now if the first pass zeroed a cell
+        // of its window (else both its value and its mean are what they were, and it was
+        // no peak).  occ_skip marks the 32 x 32 cell blocks that hold first-pass peaks:
+        // nothing within reach of this block's outputs -> nothing to do here.
+        const int c_first = (int)blockIdx.x * (HT - 2 * R) - R;
+        const int c_lo = max(c_first, 0) >> 5, c_hi = min(c_first + HT - 1, w - 1) >> 5;
+        const int r_lo = max(y0 - R, 0) >> 5, r_hi = min(y1 - 1 + R, h - 1) >> 5;
+        const int nc = c_hi - c_lo + 1, cells = nc * (r_hi - r_lo + 1);
+        int any = 0;
+        for (int k = threadIdx.x; k < cells; k += HT)
+            any |= occ_skip[(size_t)(r_lo + k / nc) * occ_w + c_lo + k % nc];
+        if (!__syncthreads_or(any)) return;
+    }
     const bool live = c >= 0 && c < w;
     const float *col = q + (live ? c : 0);
     double cb = 0.0, cs = 0.0;
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restri
                     // per cell (nanmean of an empty window is NaN and compares false: cnt > 0)
                     const bool hit = cnt > 0 && (double)v * (double)cnt > (double)factor * (sb - ss);
                     if (found) found[o] = hit ? 1 : 0;
+                    if (occ_mark && hit) occ_mark[(size_t)(yy >> 5) * occ_w + (c >> 5)] = 1;
                     if (total && hit) total[o] = (uint8_t)(total[o] + 1);
                     if (q_out) q_out[o] = hit ? v * 0.0f : v;
                 }
@@ -553,8 +571,9 @@ int check_window(int window, int h, int w)
 
 // One BlanksFourier pass on a device quadrant: q_out <- q with the peaks zeroed (NULL: not
 // needed), found / total as in detect_kernel.
+// occ_mark / occ_skip: ((h + 31) / 32) x ((w + 31) / 32) bytes, see the kernel; either may be NULL.
 int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8_t *found,
-                uint8_t *total)
+                uint8_t *total, uint8_t *occ_mark = nullptr, const uint8_t *occ_skip = nullptr)
 {
     // rows one block walks: long runs amortise the 2R-row start-up of the sliding sums,
     // short ones fill the chip on small quadrants (aim for >= 2048 blocks of 4 waves)
@@ -564,7 +583,8 @@ int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_DETECT, (int64_t)h * w);
         hipLaunchKernelGGL((hollow_detect_kernel<27, 2>), dim3(bx, (h + seg - 1) / seg), dim3(HT),
-                           0, ctx->stream, q, h, w, 4.0f, seg, q_out, found, total);
+                           0, ctx->stream, q, h, w, 4.0f, seg, q_out, found, total, occ_mark, occ_skip,
+                           (w + 31) / 32);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
@@ -655,7 +675,8 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
     // one allocation, carved up: spectrum | quadrant and its copy without the first pass's
     // peaks | 4 byte masks | partial sums + mean
     const size_t qn8 = (qn + 15) / 16 * 16;     // (keeps every view 16-byte aligned)
-    const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(float) + 4 * qn8 +
+    const size_t occ_bytes = ((size_t)((g.qh + 31) / 32) * ((g.qw + 31) / 32) + 15) / 16 * 16;
+    const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(float) + 4 * qn8 + occ_bytes +
                          (SUM_BLOCKS + 1) * sizeof(double);
     hdem_fourier_state *fs = ctx->fourier;
     if (!fs->scratch) HDEM_HIP_CHECK(hipMalloc(&fs->scratch, bytes));
@@ -664,7 +685,8 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
         q1{(char *)q.p + qn8 * sizeof(float)}, det{(char *)q1.p + qn8 * sizeof(float)},
         iso{(char *)det.p + qn8},
         exp{(char *)iso.p + qn8}, exp2{(char *)exp.p + qn8};
-    double *partial = (double *)((char *)exp2.p + qn8), *mean = partial + SUM_BLOCKS;
+    uint8_t *occ = (uint8_t *)exp2.p + qn8;                 // 32 x 32 blocks with first-pass peaks
+    double *partial = (double *)(occ + occ_bytes), *mean = partial + SUM_BLOCKS;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_POINT, (int64_t)n);
         const size_t step = n >> 20 ? n >> 20 : 1;
@@ -692,11 +714,12 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
                                (const float2 *)F.p, g, second, (float *)q.p);
         }
         HDEM_HIP_CHECK(hipMemsetAsync(det.p, 0, qn, st));
+        HDEM_HIP_CHECK(hipMemsetAsync(occ, 0, occ_bytes, st));
         if (int rc = blanks_pass(ctx, (const float *)q.p, g.qh, g.qw, (float *)q1.p, nullptr,
-                                 (uint8_t *)det.p))
+                                 (uint8_t *)det.p, occ, nullptr))
             return rc;
         if (int rc = blanks_pass(ctx, (const float *)q1.p, g.qh, g.qw, nullptr, nullptr,
-                                 (uint8_t *)det.p))
+                                 (uint8_t *)det.p, nullptr, occ))
             return rc;
         HDEM_HIP_CHECK(hipMemsetAsync(e, 0, qn, st));
         {
