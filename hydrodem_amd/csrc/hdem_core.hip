@@ -3,6 +3,8 @@
 
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -133,12 +135,37 @@ extern "C" int hdem_free(hdem_ctx *ctx, void *dptr)
     return HDEM_OK;
 }
 
+// A device-to-host copy into memory the process has never touched (a fresh np.empty) runs
+// at 10-17 GB/s instead of 56: the copy engine's staging path takes the page faults one by
+// one.  Taking them first, on many threads, costs a few milliseconds per GiB -- the whole
+// destination range is about to be overwritten, so writing one byte per page is harmless.
+static void prefault_host(void *dst, size_t bytes)
+{
+    constexpr size_t PAGE = 4096, MIN_BYTES = (size_t)32 << 20;
+    if (bytes < MIN_BYTES) return;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    nthreads = nthreads ? (nthreads > 16 ? 16 : nthreads) : 4;
+    char *base = static_cast<char *>(dst);
+    const size_t per = (bytes / nthreads + PAGE - 1) / PAGE * PAGE;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+        if (lo >= hi) break;
+        pool.emplace_back([base, lo, hi] {
+            for (size_t o = lo; o < hi; o += PAGE) *reinterpret_cast<volatile char *>(base + o) = 0;
+            *reinterpret_cast<volatile char *>(base + hi - 1) = 0;
+        });
+    }
+    for (auto &th : pool) th.join();
+}
+
 static int copy_sync(hdem_ctx *ctx, void *dst, const void *src, size_t bytes,
                      hipMemcpyKind kind)
 {
     HDEM_REQUIRE(ctx && (bytes == 0 || (dst && src)), HDEM_ERR_BAD_ARG,
                  "null argument");
     if (!bytes) return HDEM_OK;
+    if (kind == hipMemcpyDeviceToHost) prefault_host(dst, bytes);
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     HDEM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
     if (kind != hipMemcpyDeviceToDevice)
