@@ -163,7 +163,10 @@ int ensure_plans(hdem_ctx *ctx, int H, int W)
         HDEM_REQUIRE(rc2 == 0, HDEM_ERR_HIP, "rocfft_plan_create (real forward %d x %d) failed",
                      H, W);
     }
-    {   // optional: without them the destripe keeps using the 2-D inverse plan
+    // (powers of two only -- 8192^2: 2.4 against 2.6 ms for the whole destripe, 16384^2: 8.9
+    // against 9.5; at 6000^2 and 12000^2 rocFFT's 2-D plan takes a route without the
+    // transposes and is as fast or faster: 3.1 against 3.4 ms at 6000^2)
+    if ((W & (W - 1)) == 0 && (H & (H - 1)) == 0) {
         const size_t lw[1] = {(size_t)W}, lh[1] = {(size_t)H};
         if (g_fft.plan_create(&s->inv_rows, ROCFFT_INPLACE, ROCFFT_COMPLEX_INVERSE, ROCFFT_SINGLE, 1,
                               lw, (size_t)H, nullptr) != 0)
@@ -876,7 +879,7 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
     }
     HDEM_HIP_CHECK(hipGetLastError());
     const double scale = 1.0 / ((double)H * (double)W);
-    if (fs->inv_rows && fs->inv_cols) {
+    if (fs->inv_rows && fs->inv_cols && !getenv("HDEM_FFT_2D_INVERSE")) {   // (env: experiments)
         // the transposed intermediate: rocFFT's work buffer when it is large enough (the
         // 1-D plans need none of it), else a buffer of its own
         float2 *G = !fs->split_needs_work && fs->work_bytes >= n * sizeof(float2) ? (float2 *)fs->work

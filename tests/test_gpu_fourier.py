@@ -102,6 +102,22 @@ def test_destripe_on_a_larger_raster_against_the_oracle():
         assert spec_out[win].max() < 0.01 * spec_in[win].max()
 
 
+@pytest.mark.parametrize("shape", [(512, 1024), (256, 256)])
+def test_destripe_power_of_two_sizes_take_the_split_inverse(shape, monkeypatch):
+    """For power-of-two sizes the inverse transform runs as two batched 1-D passes with
+    own transposes (the last one fused with the abs) instead of rocFFT's 2-D plan: same
+    mask as the oracle, elevations within the bar, and the same result as the 2-D plan
+    (HDEM_FFT_2D_INVERSE) to rounding."""
+    dem = F.synth_striped_dem(*shape, seed=9)
+    want, want_mask, _ = F.detect_apply_fourier(dem)
+    out, mask = backend.fourier_destripe(dem, return_mask=True)
+    assert np.array_equal(mask, want_mask)
+    assert np.abs(out - want).max() <= TOL
+    monkeypatch.setenv("HDEM_FFT_2D_INVERSE", "1")
+    out2 = backend.fourier_destripe(dem)
+    assert np.abs(out - out2).max() <= 2e-5
+
+
 def test_destripe_rejects_rasters_whose_quadrants_are_smaller_than_the_window():
     with pytest.raises(hd.WindowSizeHighError) as e:
         hd.DetectApplyFourier().apply(np.zeros((120, 200), dtype=np.float32))
