@@ -148,13 +148,18 @@ static void prefault_host(void *dst, size_t bytes)
     char *base = static_cast<char *>(dst);
     const size_t per = (bytes / nthreads + PAGE - 1) / PAGE * PAGE;
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthreads; ++t) {
-        const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
-        if (lo >= hi) break;
-        pool.emplace_back([base, lo, hi] {
-            for (size_t o = lo; o < hi; o += PAGE) *reinterpret_cast<volatile char *>(base + o) = 0;
-            *reinterpret_cast<volatile char *>(base + hi - 1) = 0;
-        });
+    try {
+        for (unsigned t = 0; t < nthreads; ++t) {
+            const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+            if (lo >= hi) break;
+            pool.emplace_back([base, lo, hi] {
+                for (size_t o = lo; o < hi; o += PAGE)
+                    *reinterpret_cast<volatile char *>(base + o) = 0;
+                *reinterpret_cast<volatile char *>(base + hi - 1) = 0;
+            });
+        }
+    } catch (...) {
+        // no more threads to be had: the copy takes the remaining faults itself
     }
     for (auto &th : pool) th.join();
 }
