@@ -173,15 +173,27 @@ __global__ __launch_bounds__(NT) void majority_kernel(const float *__restrict__ 
         unsigned result = 0;
         if (y >= R && y < h - R && x >= R && x < w - R) {
             const unsigned *col0 = s + ly * TW + lx;
-            const unsigned top = summary[ly * MTX + lx] >> 8;
-            unsigned cand = col0[top & 15u], votes = top >> 4;
+            // the row summaries of the window (top and bottom row: the inner segment)
+            unsigned rows[WS];
+            rows[0] = summary[ly * MTX + lx] >> 8;
 #pragma unroll
-            for (int dy = 1; dy < WS - 1; ++dy) {
-                const unsigned p = summary[(ly + dy) * MTX + lx];
-                vote_merge(col0[dy * TW + (p & 15u)], (p >> 4) & 15u, cand, votes);
+            for (int dy = 1; dy < WS - 1; ++dy) rows[dy] = summary[(ly + dy) * MTX + lx] & 0xffu;
+            rows[WS - 1] = summary[(ly + WS - 1) * MTX + lx] >> 8;
+            // A value present c times leaves at least 2 c_row - n_row votes in every row it
+            // leads and no row has negative votes, so the rows' votes add up to >= 2c - n:
+            // where they do not reach 2 need - n nothing has the share, and the merges (with
+            // their dependent reads, most of this kernel) are skipped -- all of rough terrain.
+            unsigned vote_sum = 0;
+#pragma unroll
+            for (int dy = 0; dy < WS; ++dy) vote_sum += rows[dy] >> 4;
+            unsigned cand = NAN_KEY, votes = 0;
+            if ((int)vote_sum >= 2 * need - CELLS) {
+                cand = col0[rows[0] & 15u];
+                votes = rows[0] >> 4;
+#pragma unroll
+                for (int dy = 1; dy < WS; ++dy)
+                    vote_merge(col0[dy * TW + (rows[dy] & 15u)], rows[dy] >> 4, cand, votes);
             }
-            const unsigned bottom = summary[(ly + WS - 1) * MTX + lx] >> 8;
-            vote_merge(col0[(WS - 1) * TW + (bottom & 15u)], bottom >> 4, cand, votes);
             if (cand == NAN_KEY) {
                 // no value has the share
             } else if ((int)votes >= need) {
