@@ -52,21 +52,21 @@ class ComposedFilter(Filter):  # pylint: disable=too-few-public-methods
             with DeviceRaster.from_host(image_to_filter) as raster:
                 with self.apply_device(raster) as result:
                     return result.to_host()
-        content = image_to_filter
-        for filter_ in self.filters:
-            content = filter_.apply(content)
-        return content
+        stage = image_to_filter
+        for member in self.filters:
+            stage = member.apply(stage)
+        return stage
 
     def apply_device(self, raster):
         """Chain on a device-resident raster; the caller keeps ownership of
         ``raster`` and receives a new one."""
-        content = raster
-        for filter_ in self.filters:
-            following = filter_.apply_device(content)
-            if content is not raster and content is not following:
-                content.free()      # intermediate of this chain
-            content = following
-        return content
+        stage = raster
+        for member in self.filters:
+            following = member.apply_device(stage)
+            if stage is not raster and stage is not following:
+                stage.free()        # intermediate of this chain
+            stage = following
+        return stage
 
 
 class ComposedFilterResults(Filter):  # pylint: disable=too-few-public-methods
@@ -76,12 +76,12 @@ class ComposedFilterResults(Filter):  # pylint: disable=too-few-public-methods
 
     def __init__(self):
         self.filters = []
-        self.results = dict()
+        self.results = {}
 
     def apply(self, image_to_filter):
         Filter.apply(self, image_to_filter)
-        content = image_to_filter
-        for filter_ in self.filters:
-            content = filter_.apply(content)
-            self.results[filter_.__class__.__name__] = content
-        return content
+        stage = image_to_filter
+        for member in self.filters:
+            stage = member.apply(stage)
+            self.results[type(member).__name__] = stage
+        return stage
