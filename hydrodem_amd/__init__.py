@@ -26,7 +26,8 @@ from .filters.custom_filters import (QuadraticFilter, MaskTallGroves,  # noqa: F
                                      DetectBlanksFourier, MaskFourier, FourierInitial,
                                      FourierProcessQuarters, DetectApplyFourier,
                                      MajorityFilter, CorrectNANValues, MaskNegatives,
-                                     MaskPositives, TidyingLagoons, LagoonsDetection)
+                                     MaskPositives, TidyingLagoons, LagoonsDetection,
+                                     RouteRivers, ProcessRivers, ClipLagoonsRivers)
 from .filters.extension_filters import (Convolve, Around, AbsoluteValues,  # noqa: F401
                                         FourierTransform, FourierITransform,
                                         FourierShift, FourierIShift, BitwiseXOR,

@@ -17,8 +17,20 @@ Lagoon branch: ``MajorityFilter`` :22-73, ``CorrectNANValues``
 :260-317, ``MaskNegatives`` / ``MaskPositives`` :465-510, ``TidyingLagoons``
 :564-610, ``LagoonsDetection`` :613-661.
 
+River branch (host side only -- ``RouteRivers`` is a serial scan by
+construction, SURVEY section 2 #9 / 8e "not shardable"; no kernel is wanted):
+``RouteRivers`` :128-199, ``ProcessRivers`` :770-798, ``ClipLagoonsRivers``
+:801-831.  They exist so that `image_hsheds.py:6-7,203-205` imports and runs
+unchanged when ``filters`` resolves here.
+
 New operators (the reference has neither): ``SinkFill`` and
 ``D8FlowDirection``, shaped like every other ``Filter``.
+
+Module namespace.  The reference's ``custom_filters`` is also where its callers
+pick up the element-wise and SciPy wrappers (`image_srtm.py:7-8` takes
+``BinaryClosing`` from here, `hydro_dem_process.py:20-21` ``AdditionFilter``),
+because `custom_filters.py:9-19` imports them at module level.  The imports
+below bind the same complete set of names.
 
 Storage type.  The device path stores rasters as float32 (what GDAL hands the
 reference, `image_srtm.py:125`).  The reference drifts to float64 after the
@@ -27,13 +39,20 @@ every reference stencil re-reads its input through ``astype('float32')``
 anyway (`sliding_window.py:132`).
 """
 
+import copy
+from collections import Counter  # noqa: F401  (name of the reference module's namespace)
+
 import numpy as np
 
 from . import Filter, ComposedFilter, ComposedFilterResults
-from .simple_filters import (GreaterThan, LowerThan, BooleanToInteger, ProductFilter,
-                             SubtractionFilter)
-from .extension_filters import (Convolve, Around, AbsoluteValues, FourierTransform,
-                                FourierShift, BinaryErosion, GreyDilation)
+from .simple_filters import (LowerThan, BooleanToInteger, GreaterThan,  # noqa: F401
+                             ProductFilter, SubtractionFilter, AdditionFilter)
+from .extension_filters import (BitwiseXOR, BinaryErosion, Around,  # noqa: F401
+                                BinaryClosing, GreyDilation, Convolve,
+                                FourierITransform, FourierTransform,
+                                FourierShift, FourierIShift, AbsoluteValues)
+from ..sliding_window import (SlidingWindow, CircularWindow,  # noqa: F401
+                              NoCenterWindow, IgnoreBorderInnerSliding)
 from .. import backend
 
 
@@ -517,3 +536,57 @@ class LagoonsDetection(ComposedFilterResults):  # pylint: disable=too-few-public
                         "TidyingLagoons": self.lagoons_values,
                         "MaskPositives": self.mask_lagoons}
         return self.mask_lagoons
+
+
+# ---------------------------------------------------------------------------
+# River branch (host side; SURVEY section 2 #9: serial by construction)
+# ---------------------------------------------------------------------------
+class RouteRivers(Filter):  # pylint: disable=too-few-public-methods
+    """Route a river mask downhill on a reference DEM
+    (custom_filters.py:128-199).
+
+    Every cell of the mask whose value truncates to 1 and whose
+    ``window_size`` window fits is visited in raster order; all cells of its
+    DEM window that hold the window minimum become river and are then raised
+    to 10000 in the working copy of the DEM, so a later window sees the
+    earlier ones' marks -- the one Gauss-Seidel stencil of the reference, and
+    the reason it stays on the host.  The DEM is deep-copied at construction
+    (`:163`) and read as float32 (`sliding_window.py:132`); a window holding a
+    NaN marks nothing (``window == nan`` is never true).  Returns float64."""
+
+    def __init__(self, *, window_size, dem):
+        self.window_size = window_size
+        self.dem = copy.deepcopy(dem)
+
+    def apply(self, image_to_filter):
+        mask = SlidingWindow(image_to_filter, window_size=self.window_size)
+        work = SlidingWindow(self.dem, window_size=self.window_size).grid
+        reach = self.window_size // 2
+        routed = np.zeros(self.dem.shape)
+        height, width = mask.grid.shape
+        inner = mask.grid[reach:height - reach, reach:width - reach]
+        rows, cols = np.nonzero(np.trunc(inner) == 1)           # raster order
+        for row, col in zip(rows.tolist(), cols.tolist()):
+            window = work[row:row + 2 * reach + 1, col:col + 2 * reach + 1]
+            lowest = window == np.amin(window)
+            routed[row:row + 2 * reach + 1, col:col + 2 * reach + 1][lowest] = 1
+            window[lowest] = 10000
+        return routed
+
+
+class ProcessRivers(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """Mask of positives -> expand by 3 -> route on the HydroSHEDS DEM ->
+    binary closing (custom_filters.py:770-798)."""
+
+    def __init__(self, hsheds):  # pylint: disable=super-init-not-called
+        self.filters = [MaskPositives(), ExpandFilter(window_size=3),
+                        RouteRivers(window_size=3, dem=hsheds), BinaryClosing()]
+
+
+class ClipLagoonsRivers(ComposedFilter):  # pylint: disable=too-few-public-methods
+    """Rivers minus their intersection with the lagoons: ``rivers XOR
+    (mask_lagoons * rivers)`` (custom_filters.py:801-831)."""
+
+    def __init__(self, mask_lagoons, rivers_routed_closing):  # pylint: disable=super-init-not-called
+        self.filters = [ProductFilter(factor=mask_lagoons),
+                        BitwiseXOR(operand=rivers_routed_closing)]

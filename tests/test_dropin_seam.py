@@ -1,0 +1,101 @@
+"""
+The drop-in seam (SURVEY 8b "What calls it"): every import statement the
+reference's own modules and tests make against ``filters``, ``sliding_window``
+and ``exceptions`` -- listed, with file:line, in
+tests/golden/reference_imports.json (made by parsing the reference,
+tests/golden/make_golden_imports.py) -- is executed in a fresh interpreter with
+``hydrodem_amd/dropin`` first on ``sys.path`` and must bind objects of this
+package.  No GPU, no library load: importing the operators is free.
+"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "hydrodem_amd", "dropin")
+ROWS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_imports.json"),
+                      encoding="utf-8"))
+
+
+def run(code, *extra_path):
+    head = "import sys\n" + "".join(f"sys.path.insert(0, {p!r})\n"
+                                    for p in reversed((DROPIN, ROOT) + extra_path))
+    return subprocess.run([sys.executable, "-c", head + textwrap.dedent(code)],
+                          capture_output=True, text=True, cwd="/")
+
+
+def test_the_fixture_holds_the_three_caller_lines_of_the_verdict():
+    by_where = {r["where"]: r for r in ROWS}
+    assert by_where["hydrodem/image_srtm.py:7"]["names"] == [
+        "DetectApplyFourier", "BinaryClosing", "GrovesCorrectionsIter"]
+    assert by_where["hydrodem/image_hsheds.py:6"]["names"] == [
+        "LagoonsDetection", "ClipLagoonsRivers", "ProcessRivers"]
+    assert by_where["hydrodem/hydro_dem_process.py:20"]["names"] == [
+        "SubtractionFilter", "ProductFilter", "AdditionFilter", "PostProcessingFinal"]
+
+
+@pytest.mark.parametrize("row", ROWS, ids=[r["where"] for r in ROWS])
+def test_reference_import_statement_resolves_to_this_package(row):
+    stmt = f"from {row['module']} import ({', '.join(row['names'])})"
+    code = stmt + "\n" + "\n".join(
+        f"assert {n}.__module__.startswith('hydrodem_amd.'), ({n!r}, {n}.__module__)"
+        for n in row["names"]) + "\nprint('ok')\n"
+    out = run(code)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", f"{stmt}\n{out.stderr}"
+
+
+def test_all_statements_in_one_interpreter_share_one_set_of_classes():
+    lines = []
+    for row in ROWS:
+        lines.append(f"from {row['module']} import ({', '.join(row['names'])})")
+        lines += [f"seen.setdefault({n!r}, {n}); assert seen[{n!r}] is {n}, {n!r}"
+                  for n in row["names"]]
+    out = run("seen = {}\n" + "\n".join(lines) + "\nimport hydrodem_amd\n"
+              "assert seen['GrovesCorrectionsIter'] is hydrodem_amd.GrovesCorrectionsIter\n"
+              "assert seen['Filter'] is hydrodem_amd.Filter\nprint(len(seen))\n")
+    assert out.returncode == 0 and int(out.stdout) >= 45, out.stderr
+
+
+def test_other_cguerrero_modules_still_come_from_the_reference_tree(tmp_path):
+    """``cguerrero.hydrodem.utils_dem`` (GDAL I/O, not rebuilt) must keep
+    resolving to the tree behind the drop-in; a stand-in tree plays the
+    reference here (the GPU box has none)."""
+    pkg = tmp_path / "cguerrero" / "hydrodem"
+    (pkg / "filters").mkdir(parents=True)
+    (tmp_path / "cguerrero" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "utils_dem.py").write_text("WHO = 'reference tree'\n")
+    (pkg / "sliding_window.py").write_text("raise ImportError('shadowed module was imported')\n")
+    (pkg / "filters" / "__init__.py").write_text("raise ImportError('shadowed package')\n")
+    out = run("""
+        from cguerrero.hydrodem.utils_dem import WHO
+        from cguerrero.hydrodem.filters.custom_filters import RouteRivers, QuadraticFilter
+        from cguerrero.hydrodem.sliding_window import SlidingWindow
+        from cguerrero.hydrodem.exceptions import WindowSizeEvenError
+        import hydrodem_amd
+        assert WHO == 'reference tree'
+        assert QuadraticFilter is hydrodem_amd.QuadraticFilter
+        assert SlidingWindow is hydrodem_amd.sliding_window.SlidingWindow
+        print('ok')
+        """, str(tmp_path))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_custom_filters_namespace_covers_the_reference_module():
+    """Every public class the reference's custom_filters binds at module level
+    (its own 22 + what custom_filters.py:9-19 imports) exists here."""
+    names = sorted({n for r in ROWS if r["where"].startswith("hydrodem/filters/custom_filters.py")
+                    for n in r["names"]})
+    own = ["MajorityFilter", "ExpandFilter", "RouteRivers", "QuadraticFilter", "CorrectNANValues",
+           "IsolatedPoints", "BlanksFourier", "DetectBlanksFourier", "MaskNegatives",
+           "MaskPositives", "MaskTallGroves", "MaskFourier", "TidyingLagoons", "LagoonsDetection",
+           "GrovesCorrection", "GrovesCorrectionsIter", "ProcessRivers", "ClipLagoonsRivers",
+           "FourierInitial", "FourierProcessQuarters", "DetectApplyFourier", "PostProcessingFinal"]
+    out = run("import filters.custom_filters as m\n"
+              f"missing = [n for n in {names + own!r} if not hasattr(m, n)]\n"
+              "assert not missing, missing\nprint('ok')\n")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
