@@ -44,6 +44,8 @@ The local solver is injected (``solver=``): the HIP backend on GPUs; the CPU
 tests pass a NumPy solver so that this exchange logic runs under ``gloo``.
 """
 
+import contextlib
+
 import numpy as np
 
 from . import backend
@@ -94,7 +96,8 @@ class HipLocalSolver:
     """Local block solver on the HIP backend; tensors are CUDA torch tensors
     whose memory the kernels use in place (no copies)."""
 
-    def __init__(self, device_index=None, slice_us=DEFAULT_SLICE_US, own_context=True):
+    def __init__(self, device_index=None, slice_us=DEFAULT_SLICE_US, own_context=True,
+                 turn=None):
         import torch
         self.torch = torch
         device_index = torch.cuda.current_device() if device_index is None else device_index
@@ -109,12 +112,25 @@ class HipLocalSolver:
             self.stream = torch.cuda.Stream()
         self.ctx.set_stream(self.stream.cuda_stream)
         self.slice_us = slice_us
+        # virtual ranks sharing one GPU (ThreadWorld) solve one at a time
+        self.turn = turn
 
-    def _enter(self):
-        self.stream.wait_stream(self.torch.cuda.current_stream())
-
-    def _exit(self):
-        self.torch.cuda.current_stream().wait_stream(self.stream)
+    @contextlib.contextmanager
+    def _call(self):
+        """Order the library's stream behind torch's current stream on the way in and
+        torch's behind the library's on the way out -- also when the call raises."""
+        if self.turn is not None:
+            self.turn.acquire()
+        try:
+            self.stream.wait_stream(self.torch.cuda.current_stream())
+            try:
+                yield
+            finally:
+                self.torch.cuda.current_stream().wait_stream(self.stream)
+        finally:
+            if self.turn is not None:
+                self.stream.synchronize()
+                self.turn.release()
 
     def _wrap(self, t, dtype):
         return backend.DeviceRaster.wrap(t.data_ptr(), tuple(t.shape), dtype,
@@ -124,21 +140,23 @@ class HipLocalSolver:
         """Returns (tile visits, whether any cell was lowered, tiles still queued).
         ``sliced``: stop after ``slice_us`` even if tiles are still queued (only
         honoured together with FILL_NO_VERIFY).  ``d8``: a uint8 tensor that receives
-        the flow directions of the filled block (the certifying pass writes them)."""
+        the flow directions of the filled block (the certifying pass writes them).
+        ``last_stats`` keeps the library's counters of the call."""
         sliced = bool(sliced and self.slice_us > 0)
-        self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
-        self._enter()
-        try:
-            if d8 is not None:
-                _, _, st = backend.sinkfill_d8_dev(self._wrap(z, np.float32), eps=eps,
-                                                   out=self._wrap(w, np.float32),
-                                                   codes=self._wrap(d8, np.uint8), flags=flags)
-            else:
-                _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
-                                             out=self._wrap(w, np.float32), flags=flags)
-        finally:
-            self.ctx.set_fill_slice_us(0)
-            self._exit()
+        with self._call():
+            self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
+            try:
+                if d8 is not None:
+                    _, _, st = backend.sinkfill_d8_dev(self._wrap(z, np.float32), eps=eps,
+                                                       out=self._wrap(w, np.float32),
+                                                       codes=self._wrap(d8, np.uint8),
+                                                       flags=flags)
+                else:
+                    _, st = backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
+                                                 out=self._wrap(w, np.float32), flags=flags)
+            finally:
+                self.ctx.set_fill_slice_us(0)
+        self.last_stats = st
         return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"], st["pending"]
 
     def set_coarse_start(self, filled, block, row_map):
@@ -148,125 +166,246 @@ class HipLocalSolver:
                                        block, row_map.data_ptr())
 
     def d8(self, w, out):
-        self._enter()
-        backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
-        self._exit()
+        with self._call():
+            backend.d8_dev(self._wrap(w, np.float32), out=self._wrap(out, np.uint8))
 
     def groves(self, img, mask, window_size, threshold, iterations):
         out = self.torch.empty_like(img)
         scratch = self.torch.empty_like(img)
-        self._enter()
-        backend.groves_dev(self._wrap(img, np.float32), self._wrap(mask, np.uint8),
-                           window_size, threshold, iterations,
-                           out=self._wrap(out, np.float32),
-                           scratch=self._wrap(scratch, np.float32))
-        self._exit()
+        with self._call():
+            backend.groves_dev(self._wrap(img, np.float32), self._wrap(mask, np.uint8),
+                               window_size, threshold, iterations,
+                               out=self._wrap(out, np.float32),
+                               scratch=self._wrap(scratch, np.float32))
         return out
 
     def boxmean(self, x, do_round):
         dt = np.float64 if x.dtype == self.torch.float64 else np.float32
         out = self.torch.empty_like(x)
-        self._enter()
-        backend.boxmean3_dev(self._wrap(x, dt), do_round, out=self._wrap(out, dt))
-        self._exit()
+        with self._call():
+            backend.boxmean3_dev(self._wrap(x, dt), do_round, out=self._wrap(out, dt))
         return out
 
     def blockmax(self, z, block):
         """Block maxima of ``z`` (contiguous rows), NaN -> FLT_MAX wall."""
         out = self.torch.empty((-(-z.shape[0] // block), -(-z.shape[1] // block)),
                                dtype=z.dtype, device=z.device)
-        self._enter()
-        backend.blockmax_dev(self._wrap(z, np.float32), block,
-                             out=self._wrap(out, np.float32))
-        self._exit()
+        with self._call():
+            backend.blockmax_dev(self._wrap(z, np.float32), block,
+                                 out=self._wrap(out, np.float32))
         return out
 
 
-def _exchange(dist, torch, w, top, bottom, rank, ghost=1):
-    """Swap boundary rows with the neighbours; returns a 2-element int32 tensor on
-    ``w``'s device, (top_changed, bottom_changed) -- not read back here, so that the
-    caller pays one host synchronisation per exchange for flags and all-reduce
-    together.  One batched isend/irecv group.  Under the gloo backend device tensors
-    are staged through the host (gloo has no device point-to-point); that is the
-    rehearsal path, RCCL moves device memory."""
-    ops, recv_top, recv_bot = [], None, None
-    h = w.shape[0]
-    stage = w.is_cuda and dist.get_backend() == "gloo"
-    buf_dev = torch.device("cpu") if stage else w.device
-    if top:
-        recv_top = torch.empty(w.shape[1], dtype=w.dtype, device=buf_dev)
-        # the row rank-1 pins is ghost rows into my block: index 2 * ghost - 1 here
-        ops.append(dist.P2POp(dist.isend, w[2 * ghost - 1].to(buf_dev).contiguous(), rank - 1))
-        ops.append(dist.P2POp(dist.irecv, recv_top, rank - 1))
-    if bottom:
-        recv_bot = torch.empty(w.shape[1], dtype=w.dtype, device=buf_dev)
-        ops.append(dist.P2POp(dist.isend, w[h - 2 * ghost].to(buf_dev).contiguous(), rank + 1))
-        ops.append(dist.P2POp(dist.irecv, recv_bot, rank + 1))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    if stage:
-        recv_top = recv_top.to(w.device) if top else None
-        recv_bot = recv_bot.to(w.device) if bottom else None
-    # NaN (nodata) never compares equal: compare bit patterns
-    flags = torch.zeros(2, dtype=torch.int32, device=w.device)
-    if top:
-        flags[0] = (recv_top.view(torch.int32) != w[0].view(torch.int32)).any()
-        w[0].copy_(recv_top)
-    if bottom:
-        flags[1] = (recv_bot.view(torch.int32) != w[h - 1].view(torch.int32)).any()
-        w[h - 1].copy_(recv_bot)
-    return flags
+class DistComm:
+    """The ranks of one ``torch.distributed`` process group (``nccl`` = RCCL over xGMI
+    on the GPUs, ``gloo`` in the CPU tests and in the one-GPU rehearsal, where device
+    rows are staged through the host: gloo has no device point-to-point).  Bulk data
+    only moves between rank r and r +- 1; the collectives are a 4-byte MAX and one small
+    all-gather."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.gloo = dist.get_backend(group) == "gloo"
+        self._host = {}                                    # staging rows under gloo, by role
+
+    def _peer(self, group_rank):
+        # P2POp addresses global ranks; under a sub-group the neighbour is not rank +- 1
+        return group_rank if self.group is None else \
+            self.dist.get_global_rank(self.group, group_rank)
+
+    def _staged(self, role, like):
+        """Host twin of a device buffer (gloo only), allocated once per role and shape."""
+        buf = self._host.get(role)
+        if buf is None or buf.shape != like.shape or buf.dtype != like.dtype:
+            buf = self.torch.empty(like.shape, dtype=like.dtype, device="cpu",
+                                   pin_memory=like.is_cuda)
+            self._host[role] = buf
+        return buf
+
+    def swap(self, send_up, send_down, recv_up, recv_down):
+        """Send ``send_up`` to rank-1 and ``send_down`` to rank+1 (``None`` = no such
+        neighbour) while receiving their counterparts into ``recv_up`` / ``recv_down``:
+        one batched isend/irecv group."""
+        dist, ops, staged = self.dist, [], []
+        for send, recv, peer, role in ((send_up, recv_up, self.rank - 1, "up"),
+                                       (send_down, recv_down, self.rank + 1, "down")):
+            if send is None:
+                continue
+            if self.gloo and send.is_cuda:
+                out = self._staged("s" + role, send)
+                out.copy_(send)
+                inp = self._staged("r" + role, recv)
+                staged.append((recv, inp))
+            else:
+                out, inp = send.contiguous(), recv
+            ops.append(dist.P2POp(dist.isend, out, self._peer(peer), self.group))
+            ops.append(dist.P2POp(dist.irecv, inp, self._peer(peer), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for recv, inp in staged:
+            recv.copy_(inp)
+
+    def all_reduce_max(self, value):
+        """MAX over the ranks of a small integer tensor (returned where it came from)."""
+        if self.gloo and value.is_cuda:
+            host = value.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.MAX, group=self.group)
+            return host.to(value.device)
+        self.dist.all_reduce(value, op=self.dist.ReduceOp.MAX, group=self.group)
+        return value
+
+    def all_gather(self, t):
+        """Equally shaped tensors of all ranks, in rank order, on ``t``'s device."""
+        src = t.cpu() if self.gloo and t.is_cuda else t.contiguous()
+        parts = [self.torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(parts, src, group=self.group)
+        return [p.to(t.device) for p in parts]
 
 
-def _exchange_and_vote(dist, torch, w, top, bottom, rank, pending, group, ghost=1):
-    """One halo exchange plus the global "is anybody still busy" vote.  Returns
+class ThreadWorld:
+    """``world`` virtual ranks inside one process, one thread each, all on the same GPU:
+    the schedule of :func:`sinkfill_distributed` -- coarse start, local solves, seam
+    exchanges, votes, certification -- runs unchanged, only the transport differs
+    (device-to-device row copies instead of RCCL).  For the default-on tests of the
+    multi-GPU configurations on a one-GPU box (BASELINE configs 4 and 5) and for
+    ``tools/emulate_ranks.py``.  Local solves take turns (``gpu_turn``): the persistent
+    fill launch wants the whole device, as it has on a node with one GPU per rank."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.gpu_turn = threading.Lock()
+        self.slots = [None] * world
+
+    def comm(self, rank):
+        return _ThreadComm(self, rank)
+
+    def run(self, fn):
+        """``fn(rank, comm)`` on every virtual rank; returns the results in rank order
+        and re-raises the first failure (the others are released from their barriers)."""
+        import threading
+        results, errors = [None] * self.world, []
+
+        def body(rank):
+            try:
+                results[rank] = fn(rank, self.comm(rank))
+            except BaseException as exc:  # pylint: disable=broad-except
+                if not isinstance(exc, threading.BrokenBarrierError):
+                    errors.append(exc)
+                self.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        if self.barrier.broken:
+            raise RuntimeError("a virtual rank left its barrier")
+        return results
+
+
+class _ThreadComm:
+    def __init__(self, world, rank):
+        self.shared, self.rank, self.world = world, rank, world.world
+        self.gpu_turn = world.gpu_turn
+
+    def _publish(self, item):
+        self.shared.slots[self.rank] = item
+        self.shared.barrier.wait()                         # everybody has published
+
+    def _done(self):
+        self.shared.barrier.wait()                         # everybody has read
+
+    def swap(self, send_up, send_down, recv_up, recv_down):
+        self._publish((send_up, send_down))
+        if send_up is not None:
+            recv_up.copy_(self.shared.slots[self.rank - 1][1])
+        if send_down is not None:
+            recv_down.copy_(self.shared.slots[self.rank + 1][0])
+        if recv_up is not None and recv_up.is_cuda:
+            import torch
+            torch.cuda.current_stream().synchronize()      # the senders may overwrite now
+        self._done()
+
+    def all_reduce_max(self, value):
+        self._publish(value)
+        out = self.shared.slots[0].clone()
+        for other in self.shared.slots[1:]:
+            out = out.maximum(other.to(out.device))
+        self._done()
+        value.copy_(out)
+        return value
+
+    def all_gather(self, t):
+        self._publish(t)
+        parts = [p.clone() for p in self.shared.slots]
+        self._done()
+        return parts
+
+
+class _Seam:
+    """Receive rows and flag words of one block's seam exchanges, allocated once per
+    distributed fill instead of once per exchange."""
+
+    def __init__(self, torch, w, top, bottom):
+        row = lambda: torch.empty(w.shape[1], dtype=w.dtype, device=w.device)
+        self.recv_top = row() if top else None
+        self.recv_bot = row() if bottom else None
+        self.word = torch.zeros(3, dtype=torch.int32, device=w.device)   # busy, top, bottom
+
+
+def _exchange_and_vote(comm, torch, w, top, bottom, pending, seam, ghost=1):
+    """One halo exchange plus the global "is anybody still busy" vote: swap the seam
+    rows with rank +- 1, note which ghost row changed (bit patterns: NaN never compares
+    equal), MAX-reduce one word.  One host read-back for all three answers.  Returns
     (any rank busy, top ghost changed, bottom ghost changed)."""
-    flags = _exchange(dist, torch, w, top, bottom, rank, ghost)
-    busy = (flags.max() + int(pending > 0)).clamp(max=1).reshape(1)
-    if dist.get_backend() == "gloo":
-        busy = busy.cpu()                       # gloo reduces host tensors
-    dist.all_reduce(busy, op=dist.ReduceOp.MAX, group=group)
-    out = torch.cat([busy.to(flags.device), flags]).cpu()          # the one read-back
+    h = w.shape[0]
+    # the row rank-1 pins is `ghost` rows into my block: index 2 * ghost - 1 here
+    comm.swap(w[2 * ghost - 1] if top else None, w[h - 2 * ghost] if bottom else None,
+              seam.recv_top, seam.recv_bot)
+    word = seam.word
+    word.zero_()
+    if top:
+        word[1] = (seam.recv_top.view(torch.int32) != w[0].view(torch.int32)).any()
+        w[0].copy_(seam.recv_top)
+    if bottom:
+        word[2] = (seam.recv_bot.view(torch.int32) != w[h - 1].view(torch.int32)).any()
+        w[h - 1].copy_(seam.recv_bot)
+    word[0] = (word[1:].max() + int(pending > 0)).clamp(max=1)
+    busy = comm.all_reduce_max(word[:1].clone())
+    out = torch.cat([busy, word[1:]]).cpu()                         # the one read-back
     return bool(out[0]), bool(out[1]), bool(out[2])
 
 
-def _all_gather(dist, torch, t, world, group):
-    """all_gather of equally shaped tensors; device tensors are staged through the
-    host under gloo (the CPU rehearsal path)."""
-    stage = t.is_cuda and dist.get_backend() == "gloo"
-    src = t.cpu() if stage else t
-    parts = [torch.empty_like(src) for _ in range(world)]
-    dist.all_gather(parts, src, group=group)
-    return [p.to(t.device) for p in parts] if stage else parts
-
-
-def coarse_start(z_local, rank, world, solver, block=COARSE_BLOCK, group=None, ghost=1):
+def coarse_start(z_local, comm, solver, block=COARSE_BLOCK, ghost=1):
     """Start values from a fill of the whole raster coarsened to block maxima (see the
     module docstring).  Returns (filled, row_map): the filled stacked coarse raster
     (every rank holds the same one) and, per row of ``z_local`` (ghost rows included),
     the coarse row that bounds it -- what ``hdem_set_fill_coarse_start`` takes."""
     import torch
-    import torch.distributed as dist
 
+    rank, world = comm.rank, comm.world
     top, bottom = rank > 0, rank < world - 1
     owned = z_local[owned_slice(rank, world, ghost)]
     mine = solver.blockmax(owned.contiguous(), block)
     # ranks own floor or ceil(H/world) rows: pad to a common shape for the all_gather
     # (each rank tells its coarse and its fine row count)
-    counts = torch.tensor([mine.shape[0] + (owned.shape[0] << 32)], dtype=torch.int64)
-    all_counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    if dist.get_backend() == "gloo":
-        dist.all_gather(all_counts, counts, group=group)
-    else:
-        dev_counts = _all_gather(dist, torch, counts.to(z_local.device), world, group)
-        all_counts = [c.cpu() for c in dev_counts]
-    fine = [int(c.item()) >> 32 for c in all_counts]
-    rows = [int(c.item()) & 0xffffffff for c in all_counts]
+    counts = torch.tensor([mine.shape[0], owned.shape[0]], dtype=torch.int64,
+                          device=z_local.device)
+    all_counts = torch.stack(comm.all_gather(counts)).cpu()
+    rows, fine = all_counts[:, 0].tolist(), all_counts[:, 1].tolist()
     padded = torch.full((max(rows), mine.shape[1]), float("inf"), dtype=mine.dtype,
                         device=mine.device)
     padded[:mine.shape[0]] = mine
-    parts = _all_gather(dist, torch, padded, world, group)
+    parts = comm.all_gather(padded)
     coarse = torch.cat([p[:n] for p, n in zip(parts, rows)]).contiguous()
     filled = torch.empty_like(coarse)
     solver.fill(coarse, filled, 0.0, backend.FILL_INIT | backend.FILL_NO_VERIFY)
@@ -284,9 +423,18 @@ def coarse_start(z_local, rank, world, solver, block=COARSE_BLOCK, group=None, g
     return filled, row_map.to(torch.int32).to(z_local.device)
 
 
+def _comm_for(rank, world, group, comm):
+    if comm is None:
+        comm = DistComm(group)
+    if (comm.rank, comm.world) != (rank, world):
+        raise ValueError(f"rank/world ({rank}/{world}) do not match the communicator "
+                         f"({comm.rank}/{comm.world})")
+    return comm
+
+
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
                          max_exchanges=100000, group=None, coarse_block=None, d8_out=None,
-                         ghost=1):
+                         ghost=1, comm=None):
     """Sink fill of a row-block partitioned raster.
 
     ``z_local``: torch tensor, local rows incl. ghost rows (see
@@ -295,9 +443,13 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     (uint8, same shape): also receives the D8 codes of the filled block, written by
     the last verifying pass (rows of ghost rows are meaningless, as in
     :func:`d8_distributed`).  ``ghost``: rows of overlap the local array was cut with
-    (:func:`local_range`, :func:`ghost_rows`); only the outermost is pinned."""
+    (:func:`local_range`, :func:`ghost_rows`); only the outermost is pinned.
+    ``group``: a ``torch.distributed`` process group (default: the world); ``comm``:
+    a ready communicator instead (:class:`DistComm`, or a :class:`ThreadWorld` rank).
+    ``info``: tile visits (``unchanged`` of them found nothing to lower), exchanges,
+    verifying passes, and ``solves`` -- (phase, tile visits) of every local solve, in
+    order."""
     import torch
-    import torch.distributed as dist
 
     top, bottom = rank > 0, rank < world - 1
     w = torch.empty_like(z_local) if w_out is None else w_out
@@ -306,39 +458,46 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         flags |= backend.FILL_GHOST_TOP
     if bottom:
         flags |= backend.FILL_GHOST_BOTTOM
-    flag_dev = None
     sliced = world > 1
     if coarse_block is None:
         # (every rank fills the whole stacked coarse raster; at 8 x 16384^2 that is
         # 8192 x 1024 cells and 1.6 ms, and 32 x 32 blocks would cost more in the fine
         # solve than they save here: 16.1 against 15.4 ms predicted)
         coarse_block = COARSE_BLOCK
+    tally = {"tile_visits": 0, "unchanged": 0, "solves": []}
+
+    def solve(phase, fill_flags, **kw):
+        v, lowered, pending = solver.fill(z_local, w, eps, fill_flags, **kw)
+        st = getattr(solver, "last_stats", None) or {}
+        tally["tile_visits"] += int(v)
+        tally["unchanged"] += int(st.get("visits_unchanged", 0))
+        tally["solves"].append((phase, int(v)))
+        return lowered, pending
+
     keep = None
-    if world > 1 and eps == 0.0 and coarse_block:
-        keep = coarse_start(z_local, rank, world, solver, coarse_block, group, ghost)
-        solver.set_coarse_start(keep[0], coarse_block, keep[1])
-    visits, _, pending = solver.fill(z_local, w, eps, flags | backend.FILL_NO_VERIFY, sliced)
+    if world > 1:
+        comm = _comm_for(rank, world, group, comm)
+        if eps == 0.0 and coarse_block:
+            keep = coarse_start(z_local, comm, solver, coarse_block, ghost)
+            solver.set_coarse_start(keep[0], coarse_block, keep[1])
+    _, pending = solve("first", flags | backend.FILL_NO_VERIFY, sliced=sliced)
     del keep                                       # (alive until the solve has consumed them)
     exchanges = verifications = 0
+    seam = _Seam(torch, w, top, bottom) if world > 1 else None
     while world > 1:
-        any_busy, ch_top, ch_bot = _exchange_and_vote(dist, torch, w, top, bottom, rank,
-                                                      pending, group, ghost)
-        if flag_dev is None:
-            flag_dev = "cpu" if dist.get_backend() == "gloo" else w.device
+        any_busy, ch_top, ch_bot = _exchange_and_vote(comm, torch, w, top, bottom, pending,
+                                                      seam, ghost)
         exchanges += 1
         if exchanges >= max_exchanges:
             raise RuntimeError("distributed sink fill did not converge")
         if not any_busy:
             # every rank is at rest: certify the whole block (round driver, all tiles
             # due); resume only if some rank still found something to lower
-            v, lowered, pending = solver.fill(z_local, w, eps,
-                                              backend.FILL_WARM | backend.FILL_SYNC_ONLY,
-                                              d8=d8_out)
-            visits += v
+            lowered, pending = solve("verify", backend.FILL_WARM | backend.FILL_SYNC_ONLY,
+                                     d8=d8_out)
             verifications += 1
-            again = torch.tensor([int(lowered)], dtype=torch.int32, device=flag_dev)
-            dist.all_reduce(again, op=dist.ReduceOp.MAX, group=group)
-            if int(again.item()) == 0:
+            seam.word[0] = int(lowered)
+            if int(comm.all_reduce_max(seam.word[:1].clone()).item()) == 0:
                 break
             continue
         if ch_top or ch_bot or pending > 0:
@@ -346,14 +505,12 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             act = backend.FILL_WARM | backend.FILL_RESUME | backend.FILL_NO_VERIFY
             act |= backend.FILL_ACT_TOP if ch_top else 0
             act |= backend.FILL_ACT_BOTTOM if ch_bot else 0
-            v, _, pending = solver.fill(z_local, w, eps, act, sliced)
-            visits += v
+            _, pending = solve("correct", act, sliced=sliced)
     if world == 1:
-        v, _, _ = solver.fill(z_local, w, eps, backend.FILL_WARM | backend.FILL_SYNC_ONLY,
-                              d8=d8_out)
-        visits += v
-    return w, {"tile_visits": int(visits), "exchanges": exchanges,
-               "verifications": verifications}
+        solve("verify", backend.FILL_WARM | backend.FILL_SYNC_ONLY, d8=d8_out)
+    return w, {"tile_visits": tally["tile_visits"], "visits_unchanged": tally["unchanged"],
+               "exchanges": exchanges, "verifications": verifications,
+               "solves": tally["solves"]}
 
 
 def d8_distributed(w_local, solver, out=None):
@@ -368,38 +525,31 @@ def d8_distributed(w_local, solver, out=None):
     return out
 
 
-def halo_exchange(owned, halo, rank, world, group=None):
+def halo_exchange(owned, halo, rank, world, group=None, comm=None):
     """Owned rows plus ``halo`` rows of each neighbour (one batched isend/irecv
     group; SURVEY 8e: D8 / box mean 1 row, quadratic 7 rows per pass).  Returns
     (extended tensor, rows on top that belong to rank-1, rows at the bottom that
     belong to rank+1).  Ranks must own at least ``halo`` rows."""
     import torch
-    import torch.distributed as dist
 
     top, bottom = rank > 0, rank < world - 1
     if owned.shape[0] < halo:
         raise ValueError(f"rank {rank} owns {owned.shape[0]} rows, fewer than the halo of {halo}")
-    stage = owned.is_cuda and dist.get_backend() == "gloo"
-    dev = torch.device("cpu") if stage else owned.device
-    ops, r_top, r_bot = [], None, None
-    if top:
-        r_top = torch.empty((halo,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=dev)
-        ops.append(dist.P2POp(dist.isend, owned[:halo].to(dev).contiguous(), rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, r_top, rank - 1, group))
-    if bottom:
-        r_bot = torch.empty((halo,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=dev)
-        ops.append(dist.P2POp(dist.isend, owned[-halo:].to(dev).contiguous(), rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, r_bot, rank + 1, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    parts = ([r_top.to(owned.device)] if top else []) + [owned] + \
-            ([r_bot.to(owned.device)] if bottom else [])
-    return torch.cat(parts).contiguous(), halo if top else 0, halo if bottom else 0
+    if world == 1:
+        return owned, 0, 0
+    comm = _comm_for(rank, world, group, comm)
+    # received straight into the extended block: no separate receive rows, no torch.cat
+    rows = owned.shape[0] + halo * (int(top) + int(bottom))
+    ext = torch.empty((rows,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=owned.device)
+    first = halo if top else 0
+    ext[first:first + owned.shape[0]].copy_(owned)
+    comm.swap(owned[:halo] if top else None, owned[-halo:] if bottom else None,
+              ext[:halo] if top else None, ext[rows - halo:] if bottom else None)
+    return ext, halo if top else 0, halo if bottom else 0
 
 
 def groves_distributed(img_owned, groves_owned, rank, world, solver, iterations=3,
-                       window_size=15, threshold=1.5, group=None):
+                       window_size=15, threshold=1.5, group=None, comm=None):
     """``GrovesCorrectionsIter`` on a row-block partitioned raster: one exchange of
     ``iterations * (window_size // 2)`` rows each way, then the fused passes run on the
     extended block and the overlap is recomputed instead of exchanged again.  Pass k
@@ -407,16 +557,16 @@ def groves_distributed(img_owned, groves_owned, rank, world, solver, iterations=
     last pass the owned rows are; the raster's own first and last rows keep the
     reference's untouched border ring because they are the block's."""
     halo = iterations * (window_size // 2)
-    img, t, b = halo_exchange(img_owned, halo, rank, world, group)
-    mask, _, _ = halo_exchange(groves_owned, halo, rank, world, group)
+    img, t, b = halo_exchange(img_owned, halo, rank, world, group, comm)
+    mask, _, _ = halo_exchange(groves_owned, halo, rank, world, group, comm)
     out = solver.groves(img, mask, window_size, threshold, iterations)
     return out[t:out.shape[0] - b]
 
 
-def boxmean_distributed(x_owned, rank, world, solver, do_round=True, group=None):
+def boxmean_distributed(x_owned, rank, world, solver, do_round=True, group=None, comm=None):
     """``PostProcessingFinal`` (3 x 3 mean, reflect at the raster border, optional
     rounding) on a row-block partitioned raster: one ghost row each way."""
-    x, t, b = halo_exchange(x_owned, 1, rank, world, group)
+    x, t, b = halo_exchange(x_owned, 1, rank, world, group, comm)
     out = solver.boxmean(x, do_round)
     return out[t:out.shape[0] - b]
 

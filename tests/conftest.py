@@ -44,12 +44,24 @@ def golden():
     return load
 
 
+def _stale(lib_path, source_dir, suffixes):
+    """The library is missing or older than one of its sources."""
+    if not os.path.exists(lib_path):
+        return True
+    built_at = os.path.getmtime(lib_path)
+    return any(os.path.getmtime(os.path.join(source_dir, f)) > built_at
+               for f in os.listdir(source_dir) if f.endswith(suffixes))
+
+
 @pytest.fixture(scope="session")
 def built():
-    """libhydrodem_hip.so + liboracle_c.so exist (compile if the tree is fresh)."""
+    """libhydrodem_hip.so + liboracle_c.so exist and are not older than their sources
+    (a stale library would test yesterday's kernels)."""
     import __graft_entry__ as g
     from hydrodem_amd import backend
-    if not os.path.exists(backend.LIB_PATH):
+    csrc = os.path.dirname(backend.LIB_PATH)
+    if _stale(backend.LIB_PATH, csrc, (".hip", ".h", "Makefile")) or \
+            _stale(backend.LIB_PATH, os.path.join(ROOT, "include"), (".h",)):
         g.build()
     from oracle import c_oracle
     c_oracle.build()

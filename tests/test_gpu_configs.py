@@ -1,0 +1,165 @@
+"""
+BASELINE.json's configurations at their exact sizes, on one GPU (default-on):
+
+  config 2   4096 x 4096, sink fill + D8 (the size below the coarse start)
+  config 3   16384 x 16384, the chain groves x3 -> sink fill -> D8, checked *as a chain*
+  config 4   32768 x 32768 cut into the 4 row blocks of 8192 (+ overlap) rows the 4-GPU run
+             uses, solved by `partition.sinkfill_distributed` itself on 4 virtual ranks
+  config 5   row blocks of 8192 x 65536 (what each of the 8 GPUs holds), two of them
+
+Configs 4 and 5 run the distributed schedule unchanged -- coarse start, local solves,
+seam exchanges, votes, certifying pass -- with threads for ranks and device row copies
+for the transport (`partition.ThreadWorld`); what a one-GPU box cannot show is RCCL
+itself.  Everything is compared bit for bit with the C priority-flood oracle of the
+undivided raster (about two minutes of host work per 10^9 cells, started in the
+background while the other tests run).
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from hydrodem_amd import backend
+import oracle
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+# --------------------------------------------------------------------------
+# the 10^9-cell rasters of configs 4 and 5 and their oracles, in the background
+# --------------------------------------------------------------------------
+CASES = {"config4": (32768, 32768, 4),            # 4 blocks of 8192 x 32768
+         "config5": (16384, 65536, 2)}            # 2 of config 5's 8192 x 65536 blocks
+
+
+def _oracle_of(h, w):
+    z = oracle.synth_dem(h, w)
+    want = c_oracle.sinkfill_pflood(z)
+    return z, want, c_oracle.d8(want)
+
+
+@pytest.fixture(scope="module")
+def big(built):
+    """Both rasters and their oracles, computed side by side in two threads (the C
+    calls and NumPy's loops release the GIL) from the first test of this file on."""
+    pool = ThreadPoolExecutor(len(CASES))
+    futures = {k: pool.submit(_oracle_of, h, w) for k, (h, w, _) in CASES.items()}
+    yield futures
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
+# --------------------------------------------------------------------------
+# config 2
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["rough", "srtm"])
+def test_config2_4096_sinkfill_d8_bit_exact(big, variant):  # (big: starts the oracle threads)
+    z = oracle.synth_dem(4096, 4096, variant=variant)
+    ctx = backend.context()
+    ctx.profile(True)
+    ctx.profile_reset()
+    wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z))
+    coarse_launches = ctx.profile_get(backend.K_FILL_COARSE)["launches"]
+    ctx.profile(False)
+    assert st["converged"] and st["async_timed_out"] == 0
+    assert coarse_launches == 0                  # below COARSE_MIN_CELLS: the +inf start
+    want = c_oracle.sinkfill_pflood(z)
+    assert np.array_equal(wd.to_host(), want)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    wd.free()
+    codes.free()
+
+
+# --------------------------------------------------------------------------
+# config 3: the chain as a chain
+# --------------------------------------------------------------------------
+def test_config3_chain_groves_fill_d8_at_16384(big):
+    n = 16384
+    dem = oracle.synth_dem(n, n)
+    groves = oracle.synth_groves(n, n)
+    img = backend.DeviceRaster.from_host(dem)
+    gd = backend.DeviceRaster.from_host(groves)
+    smooth = backend.groves_dev(img, gd, iterations=3)
+    filled, codes, st = backend.sinkfill_d8_dev(smooth)
+    assert st["converged"] and st["async_timed_out"] == 0
+    got_smooth = smooth.to_host()
+    # (1) the first link against the reference restatement, on crops (local operator)
+    rng = np.random.default_rng(11)
+    for _ in range(4):
+        y0, x0 = int(rng.integers(0, n - 300)), int(rng.integers(0, n - 300))
+        sl = (slice(y0, y0 + 300), slice(x0, x0 + 300))
+        want = c_oracle.groves_ref(dem[sl], groves[sl], 3)
+        inner = (slice(21, 279), slice(21, 279))
+        assert (np.abs(got_smooth[sl][inner] - want[inner]) > 1e-4).sum() <= 2
+    assert (got_smooth != dem).sum() > n * n // 1000        # the groves pass did something
+    # (2) the rest of the chain bit for bit: the oracle applied to what the GPU's first
+    # link handed on
+    want_fill = c_oracle.sinkfill_pflood(got_smooth)
+    assert np.array_equal(filled.to_host(), want_fill)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want_fill))
+    for r in (img, gd, smooth, filled, codes):
+        r.free()
+
+
+# --------------------------------------------------------------------------
+# configs 4 and 5: the multi-GPU partitions on virtual ranks
+# --------------------------------------------------------------------------
+def _partitioned_fill(z, world):
+    import torch
+    from hydrodem_amd import partition as P
+    h = z.shape[0]
+    ghost = P.ghost_rows(world, h)
+    assert ghost == P.GHOST_ROWS
+
+    def rank_body(rank, comm):
+        g0, g1, _, _ = P.local_range(rank, world, h, ghost)
+        assert P.row_range(rank, world, h)[1] - P.row_range(rank, world, h)[0] == 8192
+        zt = torch.from_numpy(z[g0:g1]).cuda()
+        codes = torch.empty(zt.shape, dtype=torch.uint8, device=zt.device)
+        solver = P.HipLocalSolver(0, turn=comm.gpu_turn)
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, d8_out=codes, ghost=ghost,
+                                         comm=comm)
+        torch.cuda.synchronize()
+        own = P.owned_slice(rank, world, ghost)
+        # idempotence on the block: a verifying solve of the result lowers nothing
+        again = solver.fill(zt, w, 0.0, backend.FILL_WARM | backend.FILL_SYNC_ONLY)
+        assert not again[1]
+        out = w[own].cpu().numpy(), codes[own].cpu().numpy(), info, solver.last_stats
+        solver.ctx.close()
+        return out
+
+    return P.ThreadWorld(world).run(rank_body)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_multi_gpu_partition_on_virtual_ranks_bit_exact(big, case):
+    h, w, world = CASES[case]
+    z, want_w, want_d = big[case].result()
+    got = _partitioned_fill(z, world)
+    from hydrodem_amd import partition as P
+    for rank, (w_own, d_own, info, st) in enumerate(got):
+        r0, r1 = P.row_range(rank, world, h)
+        assert np.array_equal(w_own, want_w[r0:r1]), f"{case}: fill of rank {rank} differs"
+        assert np.array_equal(d_own, want_d[r0:r1]), f"{case}: D8 of rank {rank} differs"
+        assert (w_own >= z[r0:r1]).all()
+        assert info["exchanges"] >= 2 and info["verifications"] >= 1
+        assert st["async_timed_out"] == 0
+    print(case, "exchanges", got[0][2]["exchanges"], "visits/rank",
+          [g[2]["tile_visits"] for g in got])
+
+
+def test_config4_raster_undivided_beyond_4_gib(big):
+    """The same 32768 x 32768 raster on ONE GPU, undivided: 4 GiB per array, byte offsets
+    no longer fit 32 bits and the buffer resource is re-based per window."""
+    z, want_w, want_d = big["config4"].result()
+    zd = backend.DeviceRaster.from_host(z)
+    wd, codes, st = backend.sinkfill_d8_dev(zd)
+    assert st["converged"] and st["async_timed_out"] == 0
+    assert st["round_visits"] < st["tile_visits"] // 4        # the async driver did the work
+    zd.free()
+    w = wd.to_host()
+    wd.free()
+    assert np.array_equal(w, want_w)
+    del w
+    assert np.array_equal(codes.to_host(), want_d)
+    codes.free()

@@ -129,20 +129,3 @@ def test_lagoons_full_size_on_crops():
         assert np.array_equal(fixed[sl][inner], stages["CorrectNANValues"][inner], equal_nan=True)
         assert np.array_equal(values[sl][inner], stages["TidyingLagoons"][inner])
         assert np.array_equal(mask[sl][inner] != 0, want_mask[inner] != 0)
-
-
-@pytest.mark.skipif(__import__("os").environ.get("HDEM_BIG_TESTS") != "1",
-                    reason="4 GiB raster: ~5 min of host work; set HDEM_BIG_TESTS=1")
-def test_sinkfill_beyond_4_gib_uses_the_asynchronous_driver():
-    """32768 x 32768 float32 = 4 GiB per array: byte offsets no longer fit 32 bits, the
-    buffer resource is re-based per window.  Bit for bit against the C oracle."""
-    n = 32768
-    z = oracle.synth_dem(n, n)
-    zd = backend.DeviceRaster.from_host(z)
-    wd, st = backend.sinkfill_dev(zd)
-    assert st["converged"] and st["async_timed_out"] == 0
-    assert st["round_visits"] < st["tile_visits"] // 4        # the async driver did the work
-    w = wd.to_host()
-    zd.free()
-    wd.free()
-    assert np.array_equal(w, c_oracle.sinkfill_pflood(z))

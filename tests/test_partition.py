@@ -230,3 +230,84 @@ def test_row_ranges_tile_the_raster():
                 assert 1 <= g <= max(1, H // world - 1) and (world == 1 or g <= P.GHOST_ROWS)
                 g0, g1, _, _ = P.local_range(r, world, H, g)
                 assert g0 >= 0 and g1 <= H and g0 == rows[r][0] - g * top
+
+
+# --------------------------------------------------------------------------
+# communicators: a sub-group of the world, and virtual ranks in one process
+# --------------------------------------------------------------------------
+def _subgroup_worker(rank, world, port, H, W, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        members = [0, 2]                           # global rank 1 sits this one out
+        group = dist.new_group(ranks=members)
+        if rank in members:
+            r, n = members.index(rank), len(members)
+            g0, g1, _, _ = P.local_range(r, n, H)
+            zt = torch.from_numpy(oracle.synth_dem(H, W, row0=g0, rows=g1 - g0))
+            w, info = P.sinkfill_distributed(zt, r, n, NumpyLocalSolver(), group=group,
+                                             coarse_block=4)
+            bm = P.boxmean_distributed(w[P.owned_slice(r, n)].contiguous(), r, n,
+                                       NumpyLocalSolver(), group=group)
+            np.savez(os.path.join(outdir, f"g{r}.npz"), w=w.numpy()[P.owned_slice(r, n)],
+                     bm=bm.numpy(), exchanges=info["exchanges"])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partition_over_a_sub_group_addresses_the_right_peers(tmp_path):
+    """The neighbours of a rank are its neighbours *in the group*: with the group
+    {0, 2} of a 3-process world, group rank 1 is global rank 2."""
+    H, W = 90, 64
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), H, W, str(tmp_path)), nprocs=3, join=True)
+    want = c_oracle.sinkfill_pflood(oracle.synth_dem(H, W))
+    parts = [np.load(tmp_path / f"g{r}.npz") for r in range(2)]
+    assert np.array_equal(np.concatenate([p["w"] for p in parts]), want)
+    assert np.array_equal(np.concatenate([p["bm"] for p in parts]), oracle.boxmean3_round(want))
+    with pytest.raises(ValueError, match="do not match the communicator"):
+        class Fake:                                 # pylint: disable=too-few-public-methods
+            rank, world = 0, 3
+        P.sinkfill_distributed(torch.zeros(8, 8), 1, 3, NumpyLocalSolver(), comm=Fake())
+
+
+@pytest.mark.parametrize("world,H,W,variant,ghost", [(2, 96, 80, "rough", 1),
+                                                    (4, 130, 70, "srtm", 9),
+                                                    (3, 99, 64, "rough", 62)])
+def test_virtual_ranks_in_one_process_run_the_same_schedule(world, H, W, variant, ghost):
+    """ThreadWorld: the distributed schedule with threads for ranks and row copies for
+    the transport (what the one-GPU tests of BASELINE configs 4 and 5 run on)."""
+    z = oracle.synth_dem(H, W, variant=variant)
+    ghost = P.ghost_rows(world, H, ghost)
+
+    def rank_body(rank, comm):
+        g0, g1, _, _ = P.local_range(rank, world, H, ghost)
+        zt = torch.from_numpy(z[g0:g1].copy())
+        d = torch.empty(zt.shape, dtype=torch.uint8)
+        w, info = P.sinkfill_distributed(zt, rank, world, NumpyLocalSolver(), coarse_block=4,
+                                         d8_out=d, ghost=ghost, comm=comm)
+        own = P.owned_slice(rank, world, ghost)
+        r0, r1 = P.row_range(rank, world, H)
+        gr = P.groves_distributed(torch.from_numpy(z[r0:r1].copy()),
+                                  torch.from_numpy(oracle.synth_groves(H, W)[r0:r1].copy()),
+                                  rank, world, NumpyLocalSolver(), iterations=1, comm=comm)
+        return w.numpy()[own], d.numpy()[own], info, gr.numpy()
+
+    got = P.ThreadWorld(world).run(rank_body)
+    want = c_oracle.sinkfill_pflood(z)
+    assert np.array_equal(np.concatenate([g[0] for g in got]), want)
+    assert np.array_equal(np.concatenate([g[1] for g in got]), c_oracle.d8(want))
+    assert all(g[2]["exchanges"] >= 2 and g[2]["verifications"] >= 1 for g in got)
+    assert all(g[2]["solves"][0][0] == "first" and g[2]["solves"][-1][0] == "verify" for g in got)
+    want_g = oracle.groves_exact64(z, oracle.synth_groves(H, W), 1, 15, 1.5)[0].astype(np.float32)
+    assert np.array_equal(np.concatenate([g[3] for g in got]), want_g)
+
+
+def test_a_failing_virtual_rank_releases_the_others():
+    def rank_body(rank, comm):
+        if rank == 1:
+            raise KeyError("rank 1 gives up")
+        comm.all_reduce_max(torch.zeros(1, dtype=torch.int32))
+    with pytest.raises(KeyError, match="rank 1 gives up"):
+        P.ThreadWorld(3).run(rank_body)
