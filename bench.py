@@ -7,25 +7,41 @@ bench.py -- the hot path's headline metric on MI355X.
 Metric (BASELINE.json): Mcells/s of SinkFill (to convergence) + D8FlowDirection
 on a 16384^2 float32 DEM, inputs resident in HBM when the timed region starts,
 outputs left in HBM.  One "step" = one full sink fill + D8 of the raster.
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the raster
-is N*S rows x S columns, row-block partitioned, S rows per rank -- weak
-scaling -- with halo exchange between local solves (hydrodem_amd/partition.py).
+
+N > 1: the raster is N*S rows x S columns, row-block partitioned, S rows per rank --
+weak scaling -- with seam exchanges between local solves (hydrodem_amd/partition.py),
+one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this process is one rank; started plainly (`python bench.py --gpus N`) it
+starts its N ranks itself, as fresh child processes, before anything touches a GPU.
+HDEM_REHEARSE=1 puts every rank on cuda:0 over gloo: the N > 1 code path on a one-GPU
+box, never a performance number.
 
 One JSON line on stdout (rank 0) with, besides the contract keys:
-  roofline      dominant kernel = fill_async_kernel (the sink-fill tile
-                relaxation): algorithmic bytes (12 B per cell of every tile visit:
-                Z in, W in, W out) / its HIP-event time over the timed steps, vs
-                8 TB/s HBM peak;
-  kernels       the certifying pass of the fill (which also writes the D8 codes: 9 B per
-                cell), the init kernel, the coarse pre-solve;
-  filters       the other operators of the scope table on the same raster (outside the
-                timed region);
-  cpu_baseline  the NumPy oracle (sink fill Jacobi to convergence + D8,
-                1 thread) on a bounded crop of the same DEM, same host.
+  roofline      dominant kernel = fill_async_kernel (the sink-fill tile relaxation):
+                  achieved     visit bytes / its HIP-event time over the timed steps: 12 B per
+                               cell of a visit that writes its tile back (Z in, W in, W out),
+                               8 B per cell of one that finds nothing to lower
+                  frac         achieved / 8 TB/s;  frac_of_copy: / the copy rate measured here
+                  useful_frac  the END-TO-END floor of a fill, 8 B per raster cell (Z in once,
+                               W out once), over the whole step time, / 8 TB/s -- what the
+                               schedule's revisits cost shows up here, not in `frac`
+                  traffic      HBM bytes per launch from rocprofv3 --pmc passes of this
+                               command (profiles/), null when they were taken from another
+                               build of the kernel
+  kernels       the certifying pass (also writes the D8 codes), the init kernel, the coarse
+                pre-solve, each against both roofs
+  filters       the other operators of the scope table on the same raster (outside the timed
+                region), with the NumPy / SciPy oracle timed beside them on a crop (CPU-B)
+  config2       BASELINE configs[1]: the same step at 4096^2
+  cpu_baseline  the C priority-flood oracle + C D8 on the FULL workload raster, one core;
+                the NumPy Jacobi oracle on a crop beside it (size-dependent, context only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +50,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-FILL_BYTES_PER_CELL = 12    # per tile visit: Z in + W in + W out
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+VISIT_BYTES_WRITING = 12    # per tile cell: Z in + W in + W out
+VISIT_BYTES_UNCHANGED = 8   # a visit that lowers nothing skips the write-back
+FLOOR_BYTES_PER_CELL = 8    # a whole fill: read Z once, write W once
+FILL_KERNEL = "fill_async_kernel<false, 0>"
+TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "r02_fill_traffic.json")
+FILL_SOURCES = ("hydrodem_amd/csrc/hdem_sinkfill.hip", "hydrodem_amd/csrc/hdem_internal.h")
 
 
 def parse():
@@ -44,78 +65,172 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--size", type=int, default=16384)
-    p.add_argument("--cpu-sample", type=int, default=2048,
-                   help="edge of the crop the CPU oracle is timed on (0 = skip)")
+    p.add_argument("--cpu-sample", type=int, default=1024,
+                   help="edge of the crop the NumPy Jacobi oracle is timed on (0 = no CPU lines)")
+    p.add_argument("--no-filters", action="store_true",
+                   help="skip the untimed extras (filters, config2)")
     return p.parse_args()
 
 
-def profiled_traffic(kernel_substring):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this
-    same command (profiles/r01_bench_pmc_*.csv; FETCH_SIZE and WRITE_SIZE need separate
-    passes and cannot be collected from inside this process).  FETCH_SIZE under-reports
-    on gfx950: x1.605 is the factor measured on a kernel with the same 4-byte-per-lane
-    row loads that reads a known 1.0737 GB.  None when no profile exists."""
-    import csv
-    out = {}
-    for key, name in (("fetch", "r01_bench_pmc_fetch_size.csv"), ("write", "r01_bench_pmc_write_size.csv")):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            return None
-        for row in csv.DictReader(open(path)):
-            if kernel_substring in row["Kernel_Name"]:
-                out[key] = float(row["Per_Dispatch"]) * 1024.0
-    if "fetch" not in out or "write" not in out:
-        return None
-    return out["fetch"] * 1.605 + out["write"]
+# --------------------------------------------------------------------------
+# N > 1 without an external launcher
+# --------------------------------------------------------------------------
+def launch_ranks(n):
+    """Start the N ranks as children of this (GPU-free) process and relay rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    line, failed = b"", None
+    try:
+        pending = set(range(n))
+        while pending and failed is None:
+            for rank in sorted(pending):
+                code = procs[rank].poll()
+                if code is None:
+                    continue
+                pending.discard(rank)
+                if code != 0:
+                    failed = (rank, code)
+            if pending and failed is None:
+                time.sleep(0.2)
+        line = procs[0].stdout.read() if failed is None else b""
+    finally:
+        for p in procs:                        # a failed rank leaves the others in a collective
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if failed is not None:
+        raise SystemExit(f"bench.py: rank {failed[0]} exited with status {failed[1]}")
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
 
 
-def cpu_baseline(z_crop):
-    """NumPy oracle (the 'NumPy CPU reference' of north_star) on a crop of the
-    workload; checker code timed as a baseline, never used as product."""
+# --------------------------------------------------------------------------
+# measurement helpers
+# --------------------------------------------------------------------------
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in FILL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(size):
+    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes of
+    this command (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be collected from
+    inside this process; tools/record_traffic.py condenses them into TRAFFIC_RECORD together
+    with the hash of the kernel's source).  Null -- with the reason -- when the record is
+    missing, was taken at another size or from another build of the kernel."""
+    if not os.path.exists(TRAFFIC_RECORD):
+        return None, {"traffic_note": "no PMC record committed"}
+    rec = json.load(open(TRAFFIC_RECORD))
+    meta = {"traffic_profile_head": rec.get("head"), "traffic_kernel_hash": rec.get("kernel_hash"),
+            "traffic_source": rec.get("source")}
+    if rec.get("kernel_hash") != kernel_source_hash():
+        meta["traffic_note"] = "PMC record is of another build of the kernel: not reported"
+        return None, meta
+    if rec.get("size") != size:
+        meta["traffic_note"] = f"PMC record is of size {rec.get('size')}"
+        return None, meta
+    return rec["bytes_per_launch"], meta
+
+
+def roofs(gbs, copy_gbs):
+    return {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "frac_of_copy": gbs / copy_gbs if copy_gbs else None}
+
+
+def timed(ctx, fn, reps=3):
+    fn()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def cpu_baseline(z, jacobi_edge):
+    """The oracle timed as a baseline (checker code, never the product): C priority flood +
+    C D8 on the whole workload raster; the NumPy Jacobi oracle -- the literal "NumPy CPU
+    reference" of north_star -- only on a crop, because its cost grows with the raster's
+    diameter (sweeps to convergence), so its Mcells/s cannot be carried to another size."""
     import oracle
     from oracle import c_oracle
-    n = z_crop.size
     t = time.perf_counter()
-    w, sweeps = oracle.sinkfill_jacobi(z_crop)
-    oracle.d8_flow_direction(w)
+    w = c_oracle.sinkfill_pflood(z)
+    c_oracle.d8(w)
     dt = time.perf_counter() - t
+    out = {"value": z.size / dt / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+           "sample": f"the whole {z.shape[0]}x{z.shape[1]} workload raster: C priority-flood sink "
+                     f"fill + C D8 (oracle/hdem_oracle.c), single thread, {dt:.1f} s",
+           "host_cores": os.cpu_count()}
+    del w
+    c = min(jacobi_edge, *z.shape)
+    zc = np.ascontiguousarray(z[:c, :c])
     t = time.perf_counter()
-    w2 = c_oracle.sinkfill_pflood(z_crop)
-    c_oracle.d8(w2)
-    dt_c = time.perf_counter() - t
-    assert np.array_equal(w, w2)
-    return {"value": n / dt / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
-            "sample": f"{z_crop.shape[0]}x{z_crop.shape[1]} crop (rows/cols 0..) of the "
-                      f"workload DEM; NumPy Jacobi sink fill to convergence "
-                      f"({sweeps} sweeps) + NumPy D8, single thread, {dt:.1f} s",
-            "host_cores": os.cpu_count(),
-            "c_priority_flood": {"value": n / dt_c / 1e6, "unit": "Mcells/s", "cores": 1,
-                                 "seconds": dt_c,
-                                 "note": "same crop, C priority-flood oracle + C D8 "
-                                         "(a better CPU algorithm than the NumPy path)"}}
+    wj, sweeps = oracle.sinkfill_jacobi(zc)
+    oracle.d8_flow_direction(wj)
+    dtj = time.perf_counter() - t
+    assert np.array_equal(wj, c_oracle.sinkfill_pflood(zc))
+    out["numpy_jacobi"] = {"value": zc.size / dtj / 1e6, "unit": "Mcells/s", "cores": 1,
+                           "sample": f"{c}x{c} crop, NumPy Jacobi sink fill to convergence "
+                                     f"({sweeps} sweeps) + NumPy D8, {dtj:.1f} s",
+                           "note": "size-dependent: sweeps grow with the raster's diameter; "
+                                   "not comparable with the 16384^2 metric"}
+    return out
 
 
-def filter_paths(B, ctx, zd, scratch, S, reps=3):
-    """The other operators of the scope table on the same raster, outside the timed
-    region (they are not part of the headline metric): warm call, then ``reps`` timed."""
+def cpu_b(z, groves):
+    """BASELINE.md section 3, CPU-B: the NumPy / SciPy oracle of groves x3 and of the final
+    3x3 mean + rounding, one thread, on crops of the workload (both are local operators with
+    a size-independent cost per cell)."""
+    import oracle
+    g = 2048
+    zc, gc = np.ascontiguousarray(z[:g, :g]), np.ascontiguousarray(groves[:g, :g])
+    t = time.perf_counter()
+    oracle.groves_exact64(zc, gc, 3, 15, 1.5)
+    dt_g = time.perf_counter() - t
+    b = 4096
+    zb = np.ascontiguousarray(z[:b, :b])
+    t = time.perf_counter()
+    oracle.boxmean3_round(zb)
+    dt_b = time.perf_counter() - t
+    return ({"Mcells_per_s": zc.size / dt_g / 1e6, "cores": 1,
+             "sample": f"{g}x{g} crop, NumPy separable quadratic + groves algebra x3, {dt_g:.1f} s"},
+            {"Mcells_per_s": zb.size / dt_b / 1e6, "cores": 1,
+             "sample": f"{b}x{b} crop, scipy.ndimage.convolve + np.around, {dt_b:.1f} s"})
+
+
+def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=3):
+    """The other operators of the scope table on the same raster, outside the timed region
+    (they are not part of the headline metric): warm call, then ``reps`` timed."""
     import hdem_synth
     res = {}
 
-    def timed(fn):
-        fn()
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        ctx.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        return {"ms": ms, "Mcells_per_s": S * S / ms / 1e3}
+    def line(ms, bytes_per_cell=None):
+        out = {"ms": ms, "Mcells_per_s": S * S / ms / 1e3}
+        if bytes_per_cell:
+            out["algorithmic_bytes_per_cell"] = bytes_per_cell
+            out.update(roofs(bytes_per_cell * S * S / ms / 1e6, copy_gbs))
+        return out
 
-    mask = B.DeviceRaster.from_host(hdem_synth.synth_groves(S, S), ctx=ctx)
+    groves_host = hdem_synth.synth_groves(S, S)
+    mask = B.DeviceRaster.from_host(groves_host, ctx=ctx)
     pong = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
-    res["groves_x3"] = dict(timed(lambda: B.groves_dev(zd, mask, iterations=3, out=scratch,
-                                                       scratch=pong)),
-                            algorithmic_bytes_per_cell=27)
+    res["groves_x3"] = line(timed(ctx, lambda: B.groves_dev(zd, mask, iterations=3, out=scratch,
+                                                            scratch=pong), reps), 27)
     # BASELINE configs[2]: the full chain -- groves x3, sink fill, D8 -- device resident
     filled = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
     codes = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
@@ -123,20 +238,23 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     def chain():
         B.groves_dev(zd, mask, iterations=3, out=scratch, scratch=pong)
         B.sinkfill_d8_dev(scratch, out=filled, codes=codes)
-    res["full_chain_groves_fill_d8"] = timed(chain)
-    res["d8_alone"] = dict(timed(lambda: B.d8_dev(filled, out=codes)),
-                           algorithmic_bytes_per_cell=5)
+    res["full_chain_groves_fill_d8"] = line(timed(ctx, chain, reps))
+    res["d8_alone"] = line(timed(ctx, lambda: B.d8_dev(filled, out=codes), reps), 5)
     for r in (mask, pong, filled, codes):
         r.free()
-    res["boxmean3_round"] = dict(timed(lambda: B.boxmean3_dev(zd, out=scratch)),
-                                 algorithmic_bytes_per_cell=8)
+    res["boxmean3_round"] = line(timed(ctx, lambda: B.boxmean3_dev(zd, out=scratch), reps), 8)
+    if with_cpu:
+        z_host = zd.to_host()
+        res["groves_x3"]["cpu_numpy_oracle"], res["boxmean3_round"]["cpu_scipy_oracle"] = \
+            cpu_b(z_host, groves_host)
+        del z_host
+    del groves_host
     ctx.profile(True)
     ctx.profile_reset()
-    res["fourier_destripe"] = timed(lambda: B.fourier_destripe_dev(zd, out=scratch))
+    res["fourier_destripe"] = line(timed(ctx, lambda: B.fourier_destripe_dev(zd, out=scratch), reps))
     n_calls = reps + 1
     for name, kid in (("rocfft_c2c", B.K_FFT), ("detect", B.K_FOURIER_DETECT),
-                      ("mask", B.K_FOURIER_MASK),
-                      ("pointwise", B.K_FOURIER_POINT)):
+                      ("mask", B.K_FOURIER_MASK), ("pointwise", B.K_FOURIER_POINT)):
         res["fourier_destripe"][name + "_ms"] = ctx.profile_get(kid)["ms"] / n_calls
     ctx.profile(False)
     # SURVEY 8d's second input variant: the same DEM in integer metres (large flats, ties)
@@ -144,8 +262,8 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     hd_ = B.DeviceRaster.from_host(hs, ctx=ctx)
     codes = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
     info = {}
-    res["sinkfill_d8_srtm_variant"] = timed(
-        lambda: info.update(B.sinkfill_d8_dev(hd_, out=scratch, codes=codes)[2]))
+    res["sinkfill_d8_srtm_variant"] = line(timed(
+        ctx, lambda: info.update(B.sinkfill_d8_dev(hd_, out=scratch, codes=codes)[2]), reps))
     res["sinkfill_d8_srtm_variant"]["tile_visits"] = info.get("tile_visits")
     codes.free()
     hd_.free()
@@ -155,14 +273,13 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     del hs
     ctx.profile(True)
     ctx.profile_reset()
-
     l_fixed = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
     l_mask = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
 
     def lagoons():
         ctx.check(ctx.lib.hdem_lagoons_detection_f32_dev(ctx.handle, hd_.ptr, S, S, l_fixed.ptr,
                                                          scratch.ptr, l_mask.ptr))
-    res["lagoons_detection"] = timed(lagoons)
+    res["lagoons_detection"] = line(timed(ctx, lagoons, reps))
     res["lagoons_detection"]["majority_ms"] = ctx.profile_get(B.K_MAJORITY)["ms"] / n_calls
     res["lagoons_detection"]["other_kernels_ms"] = ctx.profile_get(B.K_LAGOON)["ms"] / n_calls
     ctx.profile(False)
@@ -171,31 +288,52 @@ def filter_paths(B, ctx, zd, scratch, S, reps=3):
     return res
 
 
+def config2(B, ctx, steps=10):
+    """BASELINE configs[1]: 4096 x 4096, sink fill + D8 on one GPU (below the size from which
+    the fill starts from a coarse solve)."""
+    import hdem_synth
+    s = 4096
+    zd = B.DeviceRaster.from_host(hdem_synth.synth_dem(s, s), ctx=ctx)
+    wd = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
+    dd = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
+    info = {}
+    ms = timed(ctx, lambda: info.update(B.sinkfill_d8_dev(zd, out=wd, codes=dd)[2]), steps)
+    for r in (zd, wd, dd):
+        r.free()
+    return {"workload": f"{s}x{s} float32 synthetic DEM, SinkFill eps=0 + D8", "steps": steps,
+            "ms_per_step": ms, "Mcells_per_s": s * s / ms / 1e3,
+            "tile_visits_per_step": info.get("tile_visits"), "tiles": info.get("tiles"),
+            "useful_frac": FLOOR_BYTES_PER_CELL * s * s / ms / 1e6 / HBM_PEAK_GBS}
+
+
+# --------------------------------------------------------------------------
 def main():
     a = parse()
     S, N = a.size, a.gpus
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(N)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if N > 1 and world != N:
-        raise SystemExit(f"--gpus {N} needs torch.distributed.run with {N} ranks "
-                         f"(WORLD_SIZE={world})")
+    if world != N:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
 
-    import hdem_synth               # inputs; oracle/ is only touched by cpu_baseline()
+    import hdem_synth               # inputs; oracle/ is only touched by the cpu_* legs
     from hydrodem_amd import backend as B
 
+    step_stats = []                 # per timed step: visits / unchanged / ...
     if N == 1:
         ctx = B.context(0)
         z = hdem_synth.synth_dem(S, S)
         zd = B.DeviceRaster.from_host(z, ctx=ctx)
         wd = B.DeviceRaster.empty(z.shape, np.float32, ctx)
         dd = B.DeviceRaster.empty(z.shape, np.uint8, ctx)
-        info = {}
 
         def step():
             # fill + D8 in one call: the certifying pass of the fill writes the codes
             _, _, st = B.sinkfill_d8_dev(zd, out=wd, codes=dd)
-            info.update(st)
+            step_stats.append(st)
 
         def sync():
             ctx.synchronize()
@@ -206,8 +344,6 @@ def main():
         import torch
         import torch.distributed as dist
         from hydrodem_amd import partition as P
-        # HDEM_REHEARSE=1: every rank on cuda:0 over gloo -- lets the N > 1 code path
-        # be exercised on a one-GPU box; never a performance number
         rehearse = os.environ.get("HDEM_REHEARSE") == "1"
         if rehearse:
             local_rank = 0
@@ -215,21 +351,22 @@ def main():
         dist.init_process_group("gloo" if rehearse else "nccl")
         H = N * S
         ghost = P.ghost_rows(world, H)                  # one tile row of overlap per seam
-        g0, g1, top, bottom = P.local_range(rank, world, H, ghost)
+        g0, g1, _, _ = P.local_range(rank, world, H, ghost)
         z = hdem_synth.synth_dem(H, S, row0=g0, rows=g1 - g0)
         dev = torch.device("cuda", local_rank)
         zt = torch.from_numpy(z).to(dev)
         wt = torch.empty_like(zt)
         dt_ = torch.empty(zt.shape, dtype=torch.uint8, device=dev)
         solver = P.HipLocalSolver(local_rank)
+        comm = P.DistComm()                             # its staging rows live across steps
         ctx = solver.ctx
-        info = {}
 
         def step():
             # (the last verifying pass of the fill writes the D8 codes of the block)
             _, st = P.sinkfill_distributed(zt, rank, world, solver, w_out=wt, d8_out=dt_,
-                                           ghost=ghost)
-            info.update(st)
+                                           ghost=ghost, comm=comm)
+            st["tiles"] = (solver.last_stats or {}).get("tiles")
+            step_stats.append(st)
 
         def sync():
             torch.cuda.synchronize()
@@ -243,6 +380,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    del step_stats[:]
     ctx.profile(True)
     ctx.profile_reset()
     sync()
@@ -258,13 +396,70 @@ def main():
     kr = ctx.profile_get(B.K_FILL_ROUND)
     ki = ctx.profile_get(B.K_FILL_INIT)
     ctx.profile(False)
+    last = step_stats[-1]
+    per_rank = None
+    if N > 1:
+        # every rank's share of the step, gathered after the timed region
+        mine = torch.tensor([kt["ms"], kc["ms"] + kb["ms"], kr["ms"], ki["ms"],
+                             float(sum(s["tile_visits"] for s in step_stats)),
+                             float(sum(s["visits_unchanged"] for s in step_stats)),
+                             float(last["tiles"] or 0), float(last["exchanges"])],
+                            dtype=torch.float64)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        if rehearse:
+            dist.all_gather(parts, mine)
+        else:
+            dev_parts = [p.to(dev) for p in parts]
+            dist.all_gather(dev_parts, mine.to(dev))
+            parts = [p.cpu() for p in dev_parts]
+        k = float(a.steps)
+        per_rank = {"fill_async_ms_per_step": [float(p[0]) / k for p in parts],
+                    "coarse_start_ms_per_step": [float(p[1]) / k for p in parts],
+                    "certify_ms_per_step": [float(p[2]) / k for p in parts],
+                    "init_ms_per_step": [float(p[3]) / k for p in parts],
+                    "tile_visits_per_step": [float(p[4]) / k for p in parts],
+                    "visits_unchanged_per_step": [float(p[5]) / k for p in parts],
+                    "tiles": [int(p[6]) for p in parts],
+                    "exchanges": [int(p[7]) for p in parts]}
 
     if rank == 0:
+        copy_gbs = B.copy_rate(ctx)
         cells_total = N * S * S
         ms_per_step = elapsed / a.steps * 1e3
-        fill_gbs = FILL_BYTES_PER_CELL * kt["units"] / max(kt["ms"], 1e-9) / 1e6
+        # rank 0's fill launches: cells of all tile visits (profile units), of which the
+        # unchanged ones skipped the write-back
+        ft2 = 62 * 62
+        unchanged_cells = sum(s["visits_unchanged"] for s in step_stats) * ft2
+        visit_bytes = VISIT_BYTES_WRITING * kt["units"] - \
+            (VISIT_BYTES_WRITING - VISIT_BYTES_UNCHANGED) * min(unchanged_cells, kt["units"])
+        fill_gbs = visit_bytes / max(kt["ms"], 1e-9) / 1e6
+        launches = max(kt["launches"], 1)
+        traffic, traffic_meta = profiled_traffic(S) if N == 1 else (None, {})
+        useful_gbs = FLOOR_BYTES_PER_CELL * cells_total / N / ms_per_step / 1e6   # per GPU
+        roofline = {"bound": "hbm", "kernel": FILL_KERNEL, "peak": HBM_PEAK_GBS}
+        roofline.update(roofs(fill_gbs, copy_gbs))
+        roofline.update({
+            "copy_rate_measured": copy_gbs,
+            "useful_frac": useful_gbs / HBM_PEAK_GBS,
+            "useful_frac_of_copy": useful_gbs / copy_gbs,
+            "end_to_end_bytes_over_floor": (visit_bytes / a.steps + 17.0 * S * S)
+                                           / (FLOOR_BYTES_PER_CELL * S * S),
+            "traffic": traffic,
+            "counter_to_algorithmic": traffic / (visit_bytes / launches) if traffic else None,
+            "launches": kt["launches"], "ms_total": kt["ms"],
+            "bytes_per_launch": visit_bytes / launches,
+            "avg_launch_ms": kt["ms"] / launches,
+            "note": "rank 0.  achieved/frac: algorithmic bytes of the tile visits (12 B per cell "
+                    "of a writing visit, 8 B of an unchanged one) over the kernel's HIP-event "
+                    "time; useful_frac: 8 B per raster cell over the whole step.  "
+                    "end_to_end_bytes_over_floor adds init (8 B/cell) and the certifying pass "
+                    "(9 B/cell)"})
+        roofline.update(traffic_meta)
+        certify_gbs = 9 * kr["units"] / max(kr["ms"], 1e-9) / 1e6
+        init_gbs = 8 * ki["units"] / max(ki["ms"], 1e-9) / 1e6
+        size_name = f"{S}^2" if N == 1 else f"{N * S}x{S}"
         out = {
-            "metric": "Mcells/s sink-fill+D8 on 16384^2 float32 DEM",
+            "metric": f"Mcells/s sink-fill+D8 on {size_name} float32 DEM",
             "value": cells_total * a.steps / elapsed / 1e6,
             "unit": "Mcells/s",
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
@@ -279,33 +474,25 @@ def main():
                                    f"SinkFill eps=0 to exact convergence + D8; "
                                    f"{S} rows per GPU, row-block partition",
                        "rows_per_gpu": S, "cols": S,
-                       "tile_visits_per_step": info.get("tile_visits"),
-                       "tiles": info.get("tiles"),
-                       "visits_unchanged": info.get("visits_unchanged"),
-                       "certifying_rounds": info.get("rounds"),
-                       "halo_exchanges": info.get("exchanges", 0)},
-            "roofline": {"bound": "hbm", "kernel": "fill_async_kernel<false, 0>",
-                         "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fill_gbs / HBM_PEAK_GBS,
-                         "traffic": profiled_traffic("fill_async_kernel<false, 0>")
-                         if (N == 1 and S == 16384) else None,
-                         "traffic_source": "profiles/r01_bench_pmc_{fetch,write}_size.csv: separate "
-                                           "rocprofv3 --pmc passes of this command, bytes per launch, "
-                                           "FETCH_SIZE x1.605 (gfx950 calibration)",
-                         "launches": kt["launches"], "ms_total": kt["ms"],
-                         "bytes_per_launch": FILL_BYTES_PER_CELL * kt["units"]
-                         / max(kt["launches"], 1),
-                         "avg_launch_ms": kt["ms"] / max(kt["launches"], 1),
-                         "note": "rank 0; algorithmic 12 B per cell of every tile visit"},
-            "kernels": {"certify_d8_kernel": {
-                            "achieved": (FILL_BYTES_PER_CELL - 4 + 1) * kr["units"]
-                            / max(kr["ms"], 1e-9) / 1e6,
-                            "unit": "GB/s", "launches": kr["launches"], "ms_total": kr["ms"],
-                            "note": "certifying pass behind the asynchronous launch, one stream "
-                                    "over the raster: reads Z and W, writes the D8 codes (1 B per "
-                                    "cell); rounds of tile visits (fill_round_kernel) only if it "
-                                    "finds a cell to lower -- then they are counted here too"},
-                        "fill_init_kernel": {"avg_launch_ms": ki["ms"] / max(ki["launches"], 1)},
+                       "tile_visits_per_step": last.get("tile_visits"),
+                       "tiles": last.get("tiles"),
+                       "visits_per_tile": (last.get("tile_visits") or 0) / max(last.get("tiles") or 1, 1),
+                       "visits_unchanged": last.get("visits_unchanged"),
+                       "visits_flat": last.get("visits_flat"),
+                       "certifying_rounds": last.get("rounds", 0),
+                       "halo_exchanges": last.get("exchanges", 0),
+                       "verifications": last.get("verifications")},
+            "roofline": roofline,
+            "kernels": {"certify_d8_kernel": dict(
+                            roofs(certify_gbs, copy_gbs), launches=kr["launches"],
+                            ms_total=kr["ms"], algorithmic_bytes_per_cell=9,
+                            note="certifying pass behind the asynchronous launch, one stream "
+                                 "over the raster: reads Z and W, writes the D8 codes; rounds of "
+                                 "tile visits (fill_round_kernel) only if it finds a cell to "
+                                 "lower -- then they are counted here too"),
+                        "fill_init_kernel": dict(
+                            roofs(init_gbs, copy_gbs), algorithmic_bytes_per_cell=8,
+                            avg_launch_ms=ki["ms"] / max(ki["launches"], 1)),
                         "coarse_pre_solve": {
                             "blockmax_avg_launch_ms": kb["ms"] / max(kb["launches"], 1),
                             "fill_async_kernel<false, 1>_avg_launch_ms":
@@ -313,15 +500,15 @@ def main():
                             "note": "fill of the 16x16 block maxima (1/256 of the cells): start "
                                     "values of the fine solve; latency-bound"}},
         }
-        if N == 1:
-            out["filters"] = filter_paths(B, ctx, zd, wd, S)
+        if per_rank:
+            out["per_rank"] = per_rank
+        if N == 1 and not a.no_filters:
+            out["filters"] = filter_paths(B, ctx, zd, wd, S, copy_gbs, bool(a.cpu_sample))
+            out["config2"] = config2(B, ctx)
         if a.cpu_sample and N == 1:
-            c = min(a.cpu_sample, S)
-            zc = np.ascontiguousarray(z[:c, :c])
-            out["cpu_baseline"] = cpu_baseline(zc)
+            out["cpu_baseline"] = cpu_baseline(z, a.cpu_sample)
         print(json.dumps(out), flush=True)
     if N > 1:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -25,11 +25,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhydrodem_hip.so")
 OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = range(8)
 
 # kernel ids for the timing query
-K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_FILL_SCAN, K_FILL_ROUND = range(8)
+K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_COPY, K_FILL_ROUND = range(8)
 K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
-K_LAGOON, K_MAJORITY, K_FILL_COARSE = 14, 15, 16
+K_LAGOON, K_MAJORITY, K_FILL_COARSE, K_FILL_FLAT = 14, 15, 16, 17
 
-FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM, FILL_NO_SCAN = 0, 1, 2, 4, 8
+FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM = 0, 1, 2, 4
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
 FILL_RESUME, FILL_GHOST_GIVEN, FILL_NO_COARSE = 0x100, 0x200, 0x400
 
@@ -43,7 +43,7 @@ class FillStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_int32), ("converged", ctypes.c_int32),
                 ("tile_visits", ctypes.c_int64), ("tiles", ctypes.c_int64),
                 ("tile_h", ctypes.c_int32), ("tile_w", ctypes.c_int32),
-                ("scans", ctypes.c_int32), ("async_timed_out", ctypes.c_int32),
+                ("visits_flat", ctypes.c_int32), ("async_timed_out", ctypes.c_int32),
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
                 ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64),
                 ("pending", ctypes.c_int64)]
@@ -81,6 +81,7 @@ SIGNATURES = {
     "hdem_sinkfill_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp,
                               _c.POINTER(FillStats)],
     "hdem_blockmax_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_copy_rate_dev": [_vp, _vp, _vp, _c.c_size_t],
     "hdem_fourier_destripe_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "hdem_fourier_destripe_f32_dev": [_vp, _vp, _i, _i, _vp, _vp],
     "hdem_blanks_fourier_f32_dev": [_vp, _vp, _i, _i, _vp],
@@ -366,6 +367,27 @@ def blockmax_dev(z, block, out=None):
     c.check(c.lib.hdem_blockmax_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], int(block),
                                         out.ptr))
     return out
+
+
+def copy_rate(ctx=None, nbytes=1 << 30, reps=5):
+    """Measured device copy rate in GB/s (bytes moved through HBM = 2 x copied bytes per
+    second): the achievable roof SURVEY 8d asks the kernels to be quoted against."""
+    c = ctx or context()
+    src = DeviceRaster.empty((nbytes // 4096, 1024), np.float32, c)
+    dst = DeviceRaster.empty(src.shape, np.float32, c)
+    try:
+        c.check(c.lib.hdem_copy_rate_dev(c.handle, src.ptr, dst.ptr, src.nbytes))   # warm
+        c.synchronize()
+        was = c.profile_get(K_COPY)
+        c.profile(True)
+        for _ in range(reps):
+            c.check(c.lib.hdem_copy_rate_dev(c.handle, src.ptr, dst.ptr, src.nbytes))
+        now = c.profile_get(K_COPY)
+        ms = now["ms"] - was["ms"]
+        return 2.0 * (now["units"] - was["units"]) / max(ms, 1e-9) / 1e6
+    finally:
+        src.free()
+        dst.free()
 
 
 def fourier_destripe_dev(dem, out=None, mask=None):

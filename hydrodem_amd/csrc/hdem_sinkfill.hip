@@ -67,12 +67,17 @@ constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on 
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
 constexpr int PEND_STRIDE = 32;    // ints: one 128-byte line per shard
 #ifdef HDEM_VISIT_PROF
-constexpr int STAT_WORDS = 14;
+constexpr int STAT_WORDS = 15;
 #else
-constexpr int STAT_WORDS = 7;      // per workgroup: visits, iterations, unchanged, re-queued,
+constexpr int STAT_WORDS = 8;      // per workgroup: visits, iterations, unchanged, re-queued,
                                    // busy ticks, idle ticks (100 MHz, async driver),
-                                   // visits made by the round driver
+                                   // visits made by the round driver, visits of flat tiles
 #endif
+constexpr int STAT_FLAT = 7;
+#ifdef HDEM_VISIT_PROF
+constexpr int STAT_PROF = 8;
+#endif
+constexpr int FLAT_NONE = 0x7f7f7f7f;  // "not flat" / "unknown" (what the 0x7f memset leaves)
 enum { ST_IDLE = 0, ST_QUEUED = 1, ST_RUNNING = 2, ST_DIRTY = 3, ST_ROUND0 = 16 };
 
 struct fill_ws {
@@ -83,6 +88,8 @@ struct fill_ws {
     int *any;           // any[r] != 0: round r has work
     int *error;
     unsigned long long *stats;   // [G][STAT_WORDS], written only by the owner
+    int *flat;          // [ntiles] float bits: level of a tile whose interior is one level
+    int *zmax;          // [ntiles] float bits: highest terrain of that interior (FLAT_NONE: -)
     int ntiles, tiles_x, tiles_y, max_rounds, G, S;
 };
 
@@ -113,6 +120,24 @@ __device__ __forceinline__ void or_less(unsigned long long &acc, float a, float 
 {
     asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_or_b64 %0, %0, vcc"
                  : "+s"(acc) : "v"(a), "v"(b) : "vcc", "scc");
+}
+
+// bit `shift` of west / east |= (a < b) in lane 0 / lane 63.  One block, so that the compare
+// mask is consumed at once (see or_changed).
+__device__ __forceinline__ void column_bits(unsigned &west, unsigned &east, float a, float b,
+                                            int shift)
+{
+    unsigned t;
+    asm volatile("v_cmp_lt_f32 vcc, %3, %4\n\t"
+                 "s_and_b32 %2, vcc_lo, 1\n\t"
+                 "s_lshl_b32 %2, %2, %5\n\t"
+                 "s_or_b32 %0, %0, %2\n\t"
+                 "s_lshr_b32 %2, vcc_hi, 31\n\t"
+                 "s_lshl_b32 %2, %2, %5\n\t"
+                 "s_or_b32 %1, %1, %2"
+                 : "+s"(west), "+s"(east), "=&s"(t)
+                 : "v"(a), "v"(b), "i"(shift)
+                 : "vcc", "scc");
 }
 
 struct scan_masks {                 // wave-uniform (SGPR) lane masks of changed cells
@@ -241,6 +266,8 @@ struct visit_result {
     bool more;         // still changing at the iteration cap: visit again
     unsigned dirs;     // bit k set: neighbour k (NW,N,NE,W,E,SW,S,SE) can use the new edge
     int iters;
+    int flat_bits;     // float bits of the level the whole interior ended at, or FLAT_NONE
+    int zmax_bits;     // ... and of the highest terrain cell under it
 };
 
 // Relax one tile to its fixed point for the current halo.  Whole wave, wave-uniform
@@ -252,7 +279,8 @@ struct visit_result {
 template <bool HAS_EPS, bool COHERENT>
 __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
                                                    int H, int W, float eps, int ty, int tx,
-                                                   float *T, uint8_t *d8 = nullptr)
+                                                   float *T, uint8_t *d8 = nullptr,
+                                                   float flat_level = HDEM_INF)
 {
     const int lane = threadIdx.x;
     const int y0 = ty * FT, x0 = tx * FT;              // window origin (= halo row/col)
@@ -297,26 +325,46 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     const bool partial = x0 + WN > W || y0 + WN > H;   // uniform: the window overhangs
     // Halo cells that sit above their own floor (z < w): only those can be lowered by a
     // new edge of mine, so only those justify waking the tile that owns them (7 % fewer
-    // visits).  The halo rows are tested here (lane masks); the halo columns' z is fetched
-    // again as lane = row vectors once the visit knows it will write (below).  (Testing
+    // visits).  Halo rows and halo columns are both tested here, while their Z is in
+    // registers (lane masks for the rows, lane = row masks for the columns).  (Testing
     // against halo values re-read after the write-back instead of the copies held since
     // the load saves another 3 % of the visits but puts 8 loads on the path to the
     // hand-off: 6.2 against 5.9 ms.)
     unsigned long long free_n = ~0ull, free_s = ~0ull;
+    unsigned fw_lo = 0, fw_hi = 0, fe_lo = 0, fe_hi = 0;
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const int y = y0 + r;
         float wc = fminf(w[r], HDEM_INF), zc = fminf(z[r], HDEM_INF);
         if (partial && (lane_out || y >= H)) { wc = HDEM_INF; zc = HDEM_INF; }
-        if (COHERENT && r == 0) free_n = __ballot(zc < wc);
-        if (COHERENT && r == WN - 1) free_s = __ballot(zc < wc);
+        if (COHERENT) {
+            // rows 0 / 63: the halo rows, one bit per lane; every row: its two halo-column
+            // cells sit in lanes 0 and 63 right now -- their bits go to row r of two
+            // lane = row masks (one compare and six scalar operations; no second, strided
+            // fetch of Z later)
+            if (r == 0) free_n = __ballot(zc < wc);
+            if (r == WN - 1) free_s = __ballot(zc < wc);
+            if (r < 32) column_bits(fw_lo, fe_lo, zc, wc, r);
+            else column_bits(fw_hi, fe_hi, zc, wc, r - 32);
+        }
         const bool row_pin = r == 0 || r == WN - 1 || y == 0 || y >= H - 1;   // uniform
         // (a pinned nodata cell has w = NaN -> +inf as well, so z = w is the wall there too)
         z[r] = (row_pin || lane_pin) ? wc : zc;
         w[r] = wc;
     }
 
+    if (COHERENT && flat_level < HDEM_INF) {
+        // the tile was last left as "flat at this level" with only its edge lines written
+        // (flat_visit): its interior in memory is stale, the level is the truth
+        const bool inner_lane = lane >= 2 && lane <= FT - 1;
+#pragma unroll
+        for (int r = 2; r <= FT - 1; ++r) w[r] = inner_lane ? flat_level : w[r];
+    }
+
+    const unsigned long long free_w = ((unsigned long long)fw_hi << 32) | fw_lo;
+    const unsigned long long free_e = ((unsigned long long)fe_hi << 32) | fe_lo;
     visit_result out;
+    out.flat_bits = out.zmax_bits = FLAT_NONE;
 #ifdef HDEM_VISIT_PROF
     for (int k = 0; k < 6; ++k) out.ticks[k] = 0;
     long long tprof_ = tprof_entry_;
@@ -352,14 +400,6 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         float c1_prev = T[lane], c62_prev = T[WN + lane];
         __syncthreads();
         float hl = HDEM_INF, hr = HDEM_INF;            // the halo columns as lane = row vectors
-        // their terrain, for the wake tests at the end (two strided loads per lane, long
-        // since back by then)
-        float zl = 0.0f, zr = 0.0f;
-        if (COHERENT) {
-            const size_t row = (size_t)min(y0 + lane, H - 1) * W;
-            zl = zg[row + min(x0, W - 1)];
-            zr = zg[row + min(x0 + WN - 1, W - 1)];
-        }
         PROF_MARK(2);
         for (; out.iters < ITER_MAX && more; ++out.iters) {
             scan_lines<HAS_EPS>(z, w, eps);            // north -> south and south -> north
@@ -474,13 +514,37 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
             or_less(west, cwest, hl);
             or_less(east, ceast, hr);
             if (COHERENT) {
-                west &= __ballot(fminf(zl, HDEM_INF) < hl);
-                east &= __ballot(fminf(zr, HDEM_INF) < hr);
+                west &= free_w;                            // (as held since the load, like hl / hr:
+                east &= free_e;                            // stale errs towards waking)
             }
             if (col1_moved && (west & mid)) out.dirs |= 1u << 3;                  // W
             if (col62_moved && (east & mid)) out.dirs |= 1u << 4;                 // E
         }
         PROF_MARK(5);
+    }
+    // ---- is the interior one flat level now?  (asynchronous driver, eps = 0) ----------------
+    // A tile under a lake: every later visit only has to compare its halo with that level
+    // (flat_visit) until the halo dips below the tile's highest terrain.  Row 31 decides
+    // cheaply for nearly every tile that is not.
+    if (COHERENT && !HAS_EPS && !partial && !more) {
+        const bool inner_lane = lane >= 1 && lane <= FT;
+        const float level = __builtin_bit_cast(
+            float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[31]), 31));
+        if ((__ballot(inner_lane && w[31] != level) == 0) && level < HDEM_INF) {
+            unsigned long long off = 0;
+            float zm = -HDEM_INF;
+#pragma unroll
+            for (int r = 1; r <= FT; ++r) {
+                or_changed(off, w[r], level);
+                zm = fmaxf(zm, z[r]);
+            }
+            if ((off & ((((1ull << FT) - 1) << 1))) == 0) {
+                zm = inner_lane ? zm : -HDEM_INF;
+                zm = -wave_min(-zm);
+                out.flat_bits = __builtin_bit_cast(int, level);
+                out.zmax_bits = __builtin_bit_cast(int, zm);
+            }
+        }
     }
     // ---- D8 of a certified tile (round driver, on request) ------------------------------
     // A visit that changes nothing has the final surface of the tile and of its halo in
@@ -584,7 +648,7 @@ __global__ __launch_bounds__(NT, 2) void fill_round_kernel(const float *__restri
                 add_stats(stats, b, v.changed, v.more, v.iters);
                 stats[(size_t)b * STAT_WORDS + 6] += 1;
 #ifdef HDEM_VISIT_PROF
-                for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 7 + k] += v.ticks[k];
+                for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + STAT_PROF + k] += v.ticks[k];
 #endif
             }
         }
@@ -736,6 +800,84 @@ __device__ __attribute__((noinline)) void async_finish(int t, int b, int G, int 
     }
 }
 
+// A visit of a tile whose interior is one flat level L (a tile under a lake) and whose
+// highest terrain cell is zmax.  Its fixed point for the halo it finds is
+//     min(L, lowest halo cell)  on every interior cell,
+// provided that minimum is not below zmax: all interior cells are connected below it, and no
+// way in is lower.  So the visit reads the 252 halo cells instead of two 64 x 64 windows and,
+// when the level drops, writes the four edge lines the neighbours read as their halo; the
+// rest of the interior is written once, behind the launch (flat_store_kernel).  Returns 0 when
+// the halo dips below the terrain -- the tile then takes the ordinary visit, which starts
+// from the level instead of the stale interior in memory.
+struct flat_result {
+    int handled;
+    bool changed;
+    unsigned dirs;
+    float level;
+};
+
+__device__ __attribute__((noinline)) flat_result flat_visit(float *wg, int H, int W, int ty, int tx,
+                                                            float L, float zmax)
+{
+    const int lane = threadIdx.x;
+    const int y0 = ty * FT, x0 = tx * FT;
+    float *wbase = wg + (size_t)y0 * W;
+    const size_t wbytes = (size_t)(H - y0) * W * sizeof(float);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        wbase, 0, (int)(unsigned)(wbytes < 0xffffffffull ? wbytes : 0xffffffffull), 0x00020000);
+    auto at = [&](int r, int c) { return (unsigned)(((size_t)r * W + x0 + c) * sizeof(float)); };
+    auto ld = [&](unsigned off) {
+        return fminf(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                         wrsrc, off, 0, AUX_SC1)), HDEM_INF);          // nodata: a wall
+    };
+    // (only tiles whose window lies inside the raster are ever flat)
+    const float top = ld(at(0, lane)), bottom = ld(at(WN - 1, lane));
+    const float left = ld(at(lane, 0)), right = ld(at(lane, WN - 1));       // lane = row
+    const float low = wave_min(fminf(fminf(top, bottom), fminf(left, right)));
+    flat_result out = {1, false, 0u, L};
+    if (low >= L) return out;                       // nothing new
+    if (low < zmax) { out.handled = 0; return out; }
+    out.changed = true;
+    out.level = low;
+    const unsigned bits = __builtin_bit_cast(unsigned, low);
+    if (lane >= 1 && lane <= FT) {
+        __builtin_amdgcn_raw_buffer_store_b32(bits, wrsrc, at(1, lane), 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b32(bits, wrsrc, at(FT, lane), 0, AUX_SC1);
+        if (lane >= 2 && lane <= FT - 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(bits, wrsrc, at(lane, 1), 0, AUX_SC1);
+            __builtin_amdgcn_raw_buffer_store_b32(bits, wrsrc, at(lane, FT), 0, AUX_SC1);
+        }
+    }
+    // wake whoever holds a cell above the new level next to it (the terrain of those cells
+    // is not at hand here: no floor filter, a few wakes too many)
+    const unsigned long long mid = ((1ull << FT) - 1) << 1, hi = 1ull << (WN - 1);
+    const unsigned long long n = __ballot(top > low), s_ = __ballot(bottom > low);
+    const unsigned long long w_ = __ballot(left > low), e = __ballot(right > low);
+    if (n & 1ull) out.dirs |= 1u << 0;
+    if (n & mid) out.dirs |= 1u << 1;
+    if (n & hi) out.dirs |= 1u << 2;
+    if (w_ & mid) out.dirs |= 1u << 3;
+    if (e & mid) out.dirs |= 1u << 4;
+    if (s_ & 1ull) out.dirs |= 1u << 5;
+    if (s_ & mid) out.dirs |= 1u << 6;
+    if (s_ & hi) out.dirs |= 1u << 7;
+    return out;
+}
+
+// The interiors of the tiles that ended the launch flat (their edge lines are in place).
+__global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int W, int tiles_x, int ntiles,
+                                                        const int *__restrict__ flat)
+{
+    const int t = blockIdx.x;
+    if (t >= ntiles || flat[t] == FLAT_NONE) return;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const float level = __builtin_bit_cast(float, flat[t]);
+    const int lane = threadIdx.x;
+    if (lane < 2 || lane > FT - 1) return;
+    float *p = wg + (size_t)(ty * FT + 2) * W + tx * FT + lane;
+    for (int r = 2; r <= FT - 1; ++r, p += W) *p = level;
+}
+
 // ROLE only names the launch (0: the raster itself, 1: the coarse pre-solve of a larger
 // raster) so that profilers list the two apart.
 template <bool HAS_EPS, int ROLE>
@@ -745,7 +887,8 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
                                                           int S, int *state, int *prio,
                                                           int *pend, int *error,
                                                           unsigned long long *stats,
-                                                          long long budget_ticks, int soft)
+                                                          long long budget_ticks, int soft,
+                                                          int *flat, int *zmax)
 {
     __shared__ float T[WN * TS];
     const int G = gridDim.x, b = blockIdx.x;
@@ -775,7 +918,38 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         t_mark = now;
         if (t < 0) break;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T);
+        // flat[t] / zmax[t] belong to whoever runs the tile; agent-scope accesses, handed on
+        // with the tile's state word like the tile itself
+        float flat_level = HDEM_INF;
+        if (!HAS_EPS) {
+            const int fb = __builtin_amdgcn_readfirstlane(ld_relaxed(flat + t));
+            if (fb != FLAT_NONE) {
+                flat_level = __builtin_bit_cast(float, fb);
+                const float zm = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readfirstlane(ld_relaxed(zmax + t)));
+                const flat_result f = flat_visit(wg, H, W, ty, tx, flat_level, zm);
+                if (f.handled) {
+                    if (f.changed && threadIdx.x == 0)
+                        __hip_atomic_store(flat + t, __builtin_bit_cast(int, f.level),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    async_finish(t, b, G, S, tiles_x, tiles_y, state, prio, pend, stats, f.changed,
+                                 false, f.dirs, 0);
+                    now = wall_clock64();
+                    if (threadIdx.x == 8) stats[(size_t)b * STAT_WORDS + STAT_FLAT] += 1;
+                    busy += now - t_mark;
+                    t_mark = now;
+                    continue;
+                }
+            }
+        }
+        const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T, nullptr,
+                                                         flat_level);
+        if (!HAS_EPS && threadIdx.x == 0 && (v.flat_bits != FLAT_NONE || flat_level < HDEM_INF)) {
+            __hip_atomic_store(flat + t, v.flat_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v.flat_bits != FLAT_NONE)
+                __hip_atomic_store(zmax + t, v.zmax_bits, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef HDEM_VISIT_PROF
         const long long t_v = wall_clock64();
 #endif
@@ -784,8 +958,8 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         now = wall_clock64();
 #ifdef HDEM_VISIT_PROF
         if (threadIdx.x == 8) {
-            for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + 7 + k] += v.ticks[k];
-            stats[(size_t)b * STAT_WORDS + 13] += (unsigned long long)(now - t_v);   // finish
+            for (int k = 0; k < 6; ++k) stats[(size_t)b * STAT_WORDS + STAT_PROF + k] += v.ticks[k];
+            stats[(size_t)b * STAT_WORDS + STAT_PROF + 6] += (unsigned long long)(now - t_v);   // finish
         }
 #endif
         busy += now - t_mark;
@@ -960,7 +1134,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     const size_t stat_ints = (size_t)ws->G * STAT_WORDS * 2;
     const size_t head = 32;                                        // error + pad (128 B)
     const size_t ints = head + stat_ints + PEND_SHARDS * PEND_STRIDE + n + 2 * gs +
-                        (size_t)max_rounds + 32;
+                        (size_t)max_rounds + 32 + 2 * n;
     const size_t bytes = ints * sizeof(int);
     if (ctx->fill_ws_bytes < bytes) {
         if (ctx->fill_ws) {
@@ -989,6 +1163,10 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     ws->state = ws->tile_key + n;
     ws->prio = ws->state + gs;
     ws->any = ws->prio + gs;
+    ws->flat = ws->any + (size_t)max_rounds + 32;
+    ws->zmax = ws->flat + n;
+    // (flat levels live inside one asynchronous launch: reset here, written out behind it)
+    HDEM_HIP_CHECK(hipMemsetAsync(ws->flat, 0x7f, 2 * n * sizeof(int), ctx->stream));
     // error, stats = 0; a resumed worklist keeps pend / state / prio of the last slice
     HDEM_HIP_CHECK(hipMemsetAsync(base, 0, (head + stat_ints) * sizeof(int), ctx->stream));
     if (!*resume) {
@@ -1140,15 +1318,21 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         if (eps != 0.0f)
             hipLaunchKernelGGL((fill_async_kernel<true, 0>), dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
         else if (ctx->in_coarse_presolve)
             hipLaunchKernelGGL((fill_async_kernel<false, 1>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
         else
             hipLaunchKernelGGL((fill_async_kernel<false, 0>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
+    }
+    if (did_async && eps == 0.0f) {
+        // tiles that ended the launch flat have only their edge lines in memory
+        hdem_scoped_timer tm(ctx, HDEM_K_FILL_FLAT, 0);
+        hipLaunchKernelGGL(flat_store_kernel, dim3(ws.ntiles), dim3(NT), 0, st, w, W, ws.tiles_x,
+                           ws.ntiles, ws.flat);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
@@ -1238,21 +1422,22 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     HDEM_HIP_CHECK(hipStreamSynchronize(st));
     unsigned long long tot[STAT_WORDS] = {};
     for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
-    ctx->stats[async_id].units += (int64_t)(tot[0] - tot[6]) * FT * FT;
+    // (visits of flat tiles touch ~500 cells, not a window: counted apart, stats->visits_flat)
+    ctx->stats[async_id].units += (int64_t)(tot[0] - tot[6] - tot[STAT_FLAT]) * FT * FT;
     ctx->stats[HDEM_K_FILL_ROUND].units += (int64_t)tot[6] * FT * FT;
     if (trace)
         fprintf(stderr, "sink fill: visits %llu iterations %llu unchanged %llu requeued %llu, "
-                        "sync rounds %d, async_error %d; async busy %.3f ms idle %.3f ms per "
-                        "workgroup (G=%d)\n", tot[0], tot[1], tot[2], tot[3], round, async_error,
+                        "flat %llu, sync rounds %d, async_error %d; async busy %.3f ms idle %.3f ms per "
+                        "workgroup (G=%d)\n", tot[0], tot[1], tot[2], tot[3], tot[STAT_FLAT], round, async_error,
                 tot[4] / 1e5 / ws.G, tot[5] / 1e5 / ws.G, ws.G);
 #ifdef HDEM_VISIT_PROF
     if (trace && tot[0])
         fprintf(stderr, "  per-visit us (sync visits): load %.2f check %.2f zt %.2f iterate %.2f "
                         "store %.2f wake-tests %.2f finish (per visit) %.2f (changed visits %llu)\n",
-                tot[7] / 100.0 / tot[0], tot[8] / 100.0 / tot[0],
-                tot[9] / 100.0 / (tot[0] - tot[2] + 1), tot[10] / 100.0 / (tot[0] - tot[2] + 1),
-                tot[11] / 100.0 / (tot[0] - tot[2] + 1), tot[12] / 100.0 / (tot[0] - tot[2] + 1),
-                tot[13] / 100.0 / tot[0], tot[0] - tot[2]);
+                tot[8] / 100.0 / tot[0], tot[9] / 100.0 / tot[0],
+                tot[10] / 100.0 / (tot[0] - tot[2] + 1), tot[11] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[12] / 100.0 / (tot[0] - tot[2] + 1), tot[13] / 100.0 / (tot[0] - tot[2] + 1),
+                tot[14] / 100.0 / tot[0], tot[0] - tot[2]);
 #endif
     if (stats) {
         stats->rounds = round;
@@ -1261,7 +1446,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         stats->tiles = ws.ntiles;
         stats->tile_h = FT;
         stats->tile_w = FT;
-        stats->scans = 0;
+        stats->visits_flat = (int32_t)tot[STAT_FLAT];
         stats->async_timed_out = async_error;
         stats->iterations = (int64_t)tot[1];
         stats->visits_unchanged = (int64_t)tot[2];

@@ -77,7 +77,7 @@ typedef enum hdem_kernel_id {
     HDEM_K_BOXMEAN = 3,
     HDEM_K_GROVES = 4,        /* fused quadratic + groves epilogue          */
     HDEM_K_CONVOLVE = 5,
-    HDEM_K_FILL_SCAN = 6,     /* (reserved)                                 */
+    HDEM_K_COPY = 6,          /* hdem_copy_rate_dev: the measured copy roof       */
     HDEM_K_FILL_ROUND = 7,    /* certifying stream + finishing rounds of tile visits */
     HDEM_K_BLOCKMAX = 8,      /* block-maximum coarsening (multi-GPU start values) */
     HDEM_K_FFT = 9,           /* rocFFT 2-D complex transform (forward or inverse) */
@@ -88,7 +88,8 @@ typedef enum hdem_kernel_id {
     HDEM_K_LAGOON = 14,         /* lagoon branch: NaN repair, morphology, dilation */
     HDEM_K_MAJORITY = 15,       /* majority vote over the circular window       */
     HDEM_K_FILL_COARSE = 16,    /* sink fill: asynchronous launch of the coarse pre-solve */
-    HDEM_K_COUNT = 17
+    HDEM_K_FILL_FLAT = 17,      /* sink fill: interiors of the tiles that ended flat      */
+    HDEM_K_COUNT = 18
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -115,7 +116,8 @@ typedef struct hdem_fill_stats {
     int64_t tile_visits;      /* tile visits, both drivers                     */
     int64_t tiles;            /* tiles in the raster                         */
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
-    int32_t scans;            /* (reserved, 0)                               */
+    int32_t visits_flat;      /* of tile_visits: tiles under one flat level, settled from
+                                 their halo ring alone (no window load)         */
     int32_t async_timed_out;  /* != 0: the asynchronous launch gave up (1 wall-clock
                                  budget, 2 workgroups not co-resident); the round driver
                                  finished the fill                              */
@@ -133,7 +135,6 @@ typedef struct hdem_fill_stats {
 #define HDEM_FILL_ACT_TOP     0x2  /* WARM: only tiles touching row 1 ...                 */
 #define HDEM_FILL_ACT_BOTTOM  0x4  /* ... and/or row H-2 start active (after a halo       */
                                    /* exchange replaced ghost row 0 / H-1)                */
-#define HDEM_FILL_NO_SCAN     0x8  /* INIT: start from +inf instead of the scan bound     */
 #define HDEM_FILL_SYNC_ONLY   0x40 /* skip the asynchronous phase (round-synchronous only) */
 #define HDEM_FILL_NO_VERIFY   0x80 /* skip the certifying pass behind the asynchronous
                                       phase: for intermediate solves of a halo-exchange loop
@@ -191,6 +192,12 @@ int hdem_set_fill_coarse_start(hdem_ctx *ctx, const float *coarse_filled, int ch
  * sink fill of z from above cell by cell -- the multi-GPU path uses it as the start value
  * of the ghost rows (new work; the reference is single process). */
 int hdem_blockmax_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, int b, float *out);
+
+/* Measurement aid ("report % of measured copy bandwidth as well as % of
+ * nominal"): a plain 16-byte-per-lane device copy of `bytes` bytes (a multiple of 16,
+ * both pointers 16-byte aligned), timed under HDEM_K_COPY (units = bytes copied); it moves
+ * 2 * bytes through HBM.  bench.py quotes every kernel against the rate it reaches. */
+int hdem_copy_rate_dev(hdem_ctx *ctx, const void *src, void *dst, size_t bytes);
 
 /* ---- A8  Fourier destripe ------------------------------------
  * DetectApplyFourier.apply, custom_filters.py:1083-1101, with FourierInitial

@@ -37,6 +37,43 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# BASELINE configs 4 and 5 on one GPU (tests/test_gpu_zz_configs.py): the rasters and
+# their C priority-flood oracles take minutes of host time, so they are made in background
+# threads from the moment the collection is known (the C calls and NumPy's loops release
+# the GIL) while the other GPU tests run.
+BIG_CASES = {"config4": (32768, 32768, 4),        # 4 row blocks of 8192 x 32768
+             "config5": (16384, 65536, 2)}        # 2 of config 5's 8192 x 65536 blocks
+
+
+def _big_oracle(h, w):
+    import oracle
+    from oracle import c_oracle
+    z = oracle.synth_dem(h, w)
+    want = c_oracle.sinkfill_pflood(z)
+    return z, want, c_oracle.d8(want)
+
+
+def pytest_collection_finish(session):
+    if not any("big" in getattr(item, "fixturenames", ()) for item in session.items):
+        return
+    if session.config.getoption("collectonly", False) or not _has_gpu():
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle
+    c_oracle.build()
+    pool = ThreadPoolExecutor(len(BIG_CASES))
+    session.config._hdem_big = (pool, {k: pool.submit(_big_oracle, h, w)
+                                       for k, (h, w, _) in BIG_CASES.items()})
+
+
+@pytest.fixture(scope="session")
+def big(request, built):
+    """{case: future of (raster, filled oracle, D8 oracle)}; see BIG_CASES."""
+    pool, futures = request.config._hdem_big
+    yield futures
+    pool.shutdown(wait=True, cancel_futures=True)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

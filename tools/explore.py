@@ -22,7 +22,7 @@ def main():
             ctx.synchronize(); tf = time.time() - t
             t = time.time(); B.d8_dev(wd, out=dd); ctx.synchronize(); td = time.time() - t
             kt = ctx.profile_get(B.K_FILL_TILE); ki = ctx.profile_get(B.K_FILL_INIT)
-            k8 = ctx.profile_get(B.K_D8); ks = ctx.profile_get(B.K_FILL_SCAN)
+            k8 = ctx.profile_get(B.K_D8); ks = ctx.profile_get(B.K_COPY)
             cells = n * n
             print(f"n={n} gen={tg:.1f}s fill={tf*1e3:.2f}ms d8={td*1e3:.3f}ms "
                   f"-> {cells/(tf+td)/1e6:.0f} Mcells/s | rounds={st['rounds']} "
