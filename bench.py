@@ -492,7 +492,9 @@ def main():
                                  "lower -- then they are counted here too"),
                         "fill_init_kernel": dict(
                             roofs(init_gbs, copy_gbs), algorithmic_bytes_per_cell=8,
-                            avg_launch_ms=ki["ms"] / max(ki["launches"], 1)),
+                            ms_per_step=ki["ms"] / a.steps,
+                            note="start values of the fine raster (and of the coarse one: two "
+                                 "launches per step)"),
                         "coarse_pre_solve": {
                             "blockmax_avg_launch_ms": kb["ms"] / max(kb["launches"], 1),
                             "fill_async_kernel<false, 1>_avg_launch_ms":
