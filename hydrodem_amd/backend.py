@@ -27,7 +27,11 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 # kernel ids for the timing query
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_COPY, K_FILL_ROUND = range(8)
 K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
-K_LAGOON, K_MAJORITY, K_FILL_COARSE, K_FILL_FLAT = 14, 15, 16, 17
+K_LAGOON, K_MAJORITY, K_FILL_COARSE, K_FILL_FLAT, K_ELEMENTWISE = 14, 15, 16, 17, 18
+
+# element-wise operators and raster types of hdem_elementwise_dev
+EW_MUL, EW_ADD, EW_RSUB, EW_GT, EW_LT, EW_NONZERO = range(6)
+_EW_TYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2}
 
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM = 0, 1, 2, 4
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
@@ -82,6 +86,7 @@ SIGNATURES = {
                               _c.POINTER(FillStats)],
     "hdem_blockmax_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_copy_rate_dev": [_vp, _vp, _vp, _c.c_size_t],
+    "hdem_elementwise_dev": [_vp, _i, _vp, _i, _vp, _i, _c.c_double, _c.c_int64, _vp, _i],
     "hdem_fourier_destripe_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "hdem_fourier_destripe_f32_dev": [_vp, _vp, _i, _i, _vp, _vp],
     "hdem_blanks_fourier_f32_dev": [_vp, _vp, _i, _i, _vp],
@@ -366,6 +371,38 @@ def blockmax_dev(z, block, out=None):
     c = z.ctx
     c.check(c.lib.hdem_blockmax_f32_dev(c.handle, z.ptr, z.shape[0], z.shape[1], int(block),
                                         out.ptr))
+    return out
+
+
+def elementwise_dev(op, image, operand, out_dtype=None, out=None):
+    """``op(image, operand)`` cell by cell on device rasters (``hdem_elementwise_dev``);
+    ``operand`` is a :class:`DeviceRaster` of the same shape or a scalar.  Result type:
+    ``out_dtype`` or, like NumPy on the stored types, uint8 for comparisons / NONZERO and
+    for a product of two masks, float64 as soon as one side is float64, else float32."""
+    c = image.ctx
+    raster = operand if isinstance(operand, DeviceRaster) else None
+    if raster is not None and raster.shape != image.shape:
+        raise ValueError(f"operand shape {raster.shape} != image shape {image.shape}")
+    if image.dtype not in _EW_TYPES or (raster is not None and raster.dtype not in _EW_TYPES):
+        raise ValueError("element-wise operators take float32, float64 or uint8 rasters")
+    if out_dtype is None:
+        kinds = [image.dtype] + ([raster.dtype] if raster is not None else [])
+        if op in (EW_GT, EW_LT, EW_NONZERO):
+            out_dtype = np.uint8
+        elif any(k == np.float64 for k in kinds):
+            out_dtype = np.float64
+        elif op == EW_MUL and all(k == np.uint8 for k in kinds) and \
+                (raster is not None or float(operand) in (0.0, 1.0)):
+            out_dtype = np.uint8
+        else:
+            out_dtype = np.float32
+    out = out or DeviceRaster.empty(image.shape, out_dtype, c)
+    n = int(np.prod(image.shape))
+    c.check(c.lib.hdem_elementwise_dev(
+        c.handle, int(op), image.ptr, _EW_TYPES[image.dtype],
+        raster.ptr if raster is not None else None,
+        _EW_TYPES[raster.dtype] if raster is not None else 0,
+        0.0 if raster is not None else float(operand), n, out.ptr, _EW_TYPES[out.dtype]))
     return out
 
 

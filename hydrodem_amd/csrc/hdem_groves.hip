@@ -399,7 +399,9 @@ int launch_pass(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, i
         HDEM_WS_CASE(17) HDEM_WS_CASE(19) HDEM_WS_CASE(21) HDEM_WS_CASE(23)
         HDEM_WS_CASE(25) HDEM_WS_CASE(27) HDEM_WS_CASE(29) HDEM_WS_CASE(31)
 #undef HDEM_WS_CASE
-        default: return HDEM_ERR_BAD_ARG;
+        default:
+            hdem_set_error("window size %d has no kernel (odd sizes 3..%d)", ws, WS_MAX);
+            return HDEM_ERR_BAD_ARG;
     }
     return HDEM_OK;
 }

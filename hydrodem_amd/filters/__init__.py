@@ -9,9 +9,17 @@ so orchestration code written against the reference keeps working when
 
 One addition: every GPU-backed filter also implements
 ``apply_device(raster)`` on a :class:`hydrodem_amd.backend.DeviceRaster`, and
-the two composed classes chain through it when every member supports it, so a
-chain pays one host->device and one device->host copy instead of one pair
-per member.
+the two composed classes chain through it, so a chain pays one host->device and
+one device->host copy instead of one pair per member.
+
+``apply(ndarray)`` keeps the reference's contract -- result types and in-place side
+effects included.  It only takes the device chain by itself when every member says
+(``auto_device``) that its device form returns exactly what its host form returns
+for a float32 raster; the element-wise operators (NumPy result types: bool, int64,
+float64) and the filters that write into their input (``CorrectNANValues``,
+``IsolatedPoints``) do not, and run member by member as in the reference.
+``apply_device`` is the explicit route: everything stays in HBM, masks are uint8,
+elevations keep the type they were uploaded with.
 """
 
 from abc import ABC, abstractmethod
@@ -32,9 +40,39 @@ class Filter(ABC):  # pylint: disable=too-few-public-methods
 
 
 def _device_chain(filters):
-    """True when every member can run device-resident."""
+    """True when every member can run device-resident and returns there what its
+    host form returns (see the module docstring)."""
     return bool(filters) and all(
-        callable(getattr(f, "apply_device", None)) for f in filters)
+        callable(getattr(f, "apply_device", None)) and getattr(f, "auto_device", False)
+        for f in filters)
+
+
+class LazyResults(dict):
+    """``results`` of a device-resident :class:`ComposedFilterResults` chain: stages stay
+    in HBM (``.device[name]``) and are copied to the host the first time somebody reads
+    them by class name, as callers of the reference do (custom_filters.py:658-660,876)."""
+
+    def __init__(self):
+        super().__init__()
+        self.device = {}
+
+    def __missing__(self, key):
+        if key not in self.device:
+            raise KeyError(key)
+        self[key] = value = self.device[key].to_host()
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.device
+
+    def keys(self):
+        return list(dict.fromkeys(list(dict.keys(self)) + list(self.device)))
+
+    def release(self):
+        """Free the device copies (host copies already made stay)."""
+        for raster in self.device.values():
+            raster.free()
+        self.device = {}
 
 
 class ComposedFilter(Filter):  # pylint: disable=too-few-public-methods
@@ -84,4 +122,18 @@ class ComposedFilterResults(Filter):  # pylint: disable=too-few-public-methods
         for member in self.filters:
             stage = member.apply(stage)
             self.results[type(member).__name__] = stage
+        return stage
+
+    def apply_device(self, raster):
+        """The chain on a device-resident raster.  Every stage stays in HBM;
+        ``results[ClassName]`` downloads a stage when it is first read
+        (:class:`LazyResults`; ``results.release()`` frees the device copies).  The
+        caller keeps ``raster``; the returned raster is the last stage, owned by
+        ``results``."""
+        lazy = LazyResults()
+        stage = raster
+        for member in self.filters:
+            stage = member.apply_device(stage)
+            lazy.device[type(member).__name__] = stage
+        self.results = lazy
         return stage

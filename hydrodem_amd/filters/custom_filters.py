@@ -63,6 +63,8 @@ class QuadraticFilter(Filter):  # pylint: disable=too-few-public-methods
     ``WindowSizeHighError`` / ``WindowSizeEvenError`` as the reference's
     ``SlidingWindow`` constructor (sliding_window.py:150-156)."""
 
+    auto_device = True      # device form == host form for a float32 raster
+
     def __init__(self, *, window_size):
         self.window_size = window_size
 
@@ -88,12 +90,18 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
         smooth = QuadraticFilter(15)(img); hl = img - smooth
         m = groves_class * (hl > 1.5);     out = hl * (1 - m) + smooth
 
-    evaluated by ONE fused HIP kernel.  ``filters`` keeps the reference's five
+    evaluated by ONE fused HIP kernel when ``groves_class`` is a 0 / 1 mask (what
+    `image_srtm.py:177-178` passes: a ``binary_closing`` result); a class raster with
+    other values takes the reference's algebra literally -- ``m = class * tall`` --
+    member by member, with only the quadratic filter on the GPU.  ``filters`` keeps
+    the reference's five
     members so that callers can still re-bind their operands
     (``filters[3].factor`` is the groves class, ``filters[0].window_size`` the
     window, ``filters[2].filters[0].value`` the tall-grove threshold); they
     are read at ``apply`` time.  ``partial_results`` is filled only with
     ``keep_partial_results=True`` (it costs an extra quadratic pass)."""
+
+    auto_device = True      # device form == host form for a float32 raster
 
     def __init__(self, groves_class, keep_partial_results=False):  # pylint: disable=super-init-not-called
         self.partial_results = []
@@ -106,9 +114,23 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
         return (self.filters[3].factor, self.filters[0].window_size,
                 self.filters[2].filters[0].value)
 
+    @staticmethod
+    def _is_mask(groves_class):
+        g = np.asarray(groves_class)
+        return g.dtype == bool or not np.any((g != 0) & (g != 1))
+
     def apply(self, image_to_filter):
         Filter.apply(self, image_to_filter)
         groves_class, window, thr = self._params()
+        if not self._is_mask(groves_class):
+            # custom_filters.py:724-732 as written: highlight * (1 - class * tall) + smooth
+            smooth = backend.quadratic(image_to_filter, window)
+            highlight = image_to_filter - smooth
+            product = groves_class * ((highlight > thr) * 1)
+            if self.keep_partial_results:
+                self.partial_results = [smooth, highlight, (highlight > thr) * 1, product,
+                                        1 - product]
+            return highlight * (1 - product) + smooth
         if self.keep_partial_results:
             img = np.ascontiguousarray(image_to_filter, dtype=np.float32)
             smooth = backend.quadratic(img, window)
@@ -120,6 +142,8 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
 
     def apply_device(self, raster):
         groves_class, window, thr = self._params()
+        if not self._is_mask(groves_class):
+            raise NotImplementedError("the fused groves kernel takes a 0 / 1 class raster")
         with backend.DeviceRaster.from_host(np.asarray(groves_class) != 0,
                                             dtype=np.uint8, ctx=raster.ctx) as g:
             out = backend.groves_dev(raster, g, window, thr, 1)
@@ -131,6 +155,8 @@ class GrovesCorrectionsIter(ComposedFilter):  # pylint: disable=too-few-public-m
     """``iterations`` chained ``GrovesCorrection`` passes
     (custom_filters.py:735-767).  When the members are untouched the whole
     chain is one C call that ping-pongs two device buffers."""
+
+    auto_device = True      # device form == host form for a float32 raster
 
     def __init__(self, groves_class, iterations=3):  # pylint: disable=super-init-not-called
         self.filters = []
@@ -147,6 +173,8 @@ class GrovesCorrectionsIter(ComposedFilter):  # pylint: disable=too-few-public-m
             p = f._params()
             if p[0] is not p0[0] or p[1:] != p0[1:]:
                 return None
+        if not GrovesCorrection._is_mask(p0[0]):
+            return None                     # member by member: the reference's algebra
         return p0
 
     def apply(self, image_to_filter):
@@ -173,6 +201,8 @@ class GrovesCorrectionsIter(ComposedFilter):  # pylint: disable=too-few-public-m
 class PostProcessingFinal(ComposedFilter):  # pylint: disable=too-few-public-methods
     """3x3 box mean then round to 1 m (custom_filters.py:1104-1125).  With the
     default members the two run as one fused kernel (float32 or float64)."""
+
+    auto_device = True      # device form == host form for a float32 raster
 
     def __init__(self):  # pylint: disable=super-init-not-called
         self.filters = [Convolve(), Around()]
@@ -216,6 +246,8 @@ class SinkFill(Filter):  # pylint: disable=too-few-public-methods
         rounds / tile_visits / tiles of the last ``apply``.
     """
 
+    auto_device = True      # device form == host form for a float32 raster
+
     def __init__(self, *, epsilon=0.0, max_rounds=0):
         self.epsilon = epsilon
         self.max_rounds = max_rounds
@@ -239,6 +271,8 @@ class D8FlowDirection(Filter):  # pylint: disable=too-few-public-methods
     ``(z_c - z_k) * w_k``, w = 1 or float32(0.70710678); ties go to the first
     neighbour in window order NW, N, NE, W, E, SW, S, SE (the order
     ``np.nonzero`` gives `custom_filters.py:193-195`).  Returns uint8."""
+
+    auto_device = True      # device form == host form for a float32 raster
 
     def apply(self, image_to_filter):
         super().apply(image_to_filter)
@@ -397,6 +431,8 @@ class DetectApplyFourier(ComposedFilter):  # pylint: disable=too-few-public-meth
     are applied straight to the spectrum.  Returns float32 (the reference: float64
     from a complex128 inverse; values agree to ~1e-5 m).  With
     ``keep_mask=True`` the full mask is kept in ``.mask`` afterwards."""
+
+    auto_device = True      # device form == host form for a float32 raster
 
     def __init__(self, keep_mask=False):  # pylint: disable=super-init-not-called
         self.initial = FourierInitial()

@@ -45,6 +45,8 @@ class Convolve(Filter):  # pylint: disable=too-few-public-methods
     computes in float32 storage.
     """
 
+    auto_device = True      # device form == host form for a float32 raster
+
     def __init__(self, weights=np.ones((3, 3))):
         self.weights = weights
 

@@ -89,7 +89,8 @@ typedef enum hdem_kernel_id {
     HDEM_K_MAJORITY = 15,       /* majority vote over the circular window       */
     HDEM_K_FILL_COARSE = 16,    /* sink fill: asynchronous launch of the coarse pre-solve */
     HDEM_K_FILL_FLAT = 17,      /* sink fill: interiors of the tiles that ended flat      */
-    HDEM_K_COUNT = 18
+    HDEM_K_ELEMENTWISE = 18,    /* element-wise operators on device rasters               */
+    HDEM_K_COUNT = 19
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -198,6 +199,27 @@ int hdem_blockmax_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, int b, fl
  * both pointers 16-byte aligned), timed under HDEM_K_COPY (units = bytes copied); it moves
  * 2 * bytes through HBM.  bench.py quotes every kernel against the rate it reaches. */
 int hdem_copy_rate_dev(hdem_ctx *ctx, const void *src, void *dst, size_t bytes);
+
+/* ---- element-wise operators ------------------------------------
+ * LowerThan / GreaterThan / BooleanToInteger / ProductFilter / AdditionFilter /
+ * SubtractionFilter.apply, simple_filters.py:7-275, on device rasters, so that the
+ * orchestration's algebra (hydro_dem_process.py:60-91, and the three-term sum in front
+ * of PostProcessingFinal, :148-149) stays in HBM between the stencils:
+ *     out[i] = op(image[i], operand ? operand[i] : scalar),  i < n.
+ * Rasters are HDEM_T_F32 / HDEM_T_F64 / HDEM_T_U8 (masks); evaluated in double, stored
+ * as out_type (comparisons and NONZERO give 0 / 1). */
+typedef enum hdem_ew_op {
+    HDEM_EW_MUL = 0,      /* operand * image      ProductFilter     :165-180 */
+    HDEM_EW_ADD = 1,      /* operand + image      AdditionFilter    :214-229 */
+    HDEM_EW_RSUB = 2,     /* operand - image      SubtractionFilter :261-275 */
+    HDEM_EW_GT = 3,       /* image > operand      GreaterThan       :81-96   */
+    HDEM_EW_LT = 4,       /* image < operand      LowerThan         :35-50   */
+    HDEM_EW_NONZERO = 5   /* image != 0           BooleanToInteger  :113-131 (bool * 1) */
+} hdem_ew_op;
+typedef enum hdem_dtype { HDEM_T_F32 = 0, HDEM_T_F64 = 1, HDEM_T_U8 = 2 } hdem_dtype;
+int hdem_elementwise_dev(hdem_ctx *ctx, int op, const void *image, int image_type,
+                         const void *operand, int operand_type, double scalar, int64_t n,
+                         void *out, int out_type);
 
 /* ---- A8  Fourier destripe ------------------------------------
  * DetectApplyFourier.apply, custom_filters.py:1083-1101, with FourierInitial
