@@ -243,12 +243,26 @@ def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=3):
     for r in (mask, pong, filled, codes):
         r.free()
     res["boxmean3_round"] = line(timed(ctx, lambda: B.boxmean3_dev(zd, out=scratch), reps), 8)
+    # the raster I/O seam: groves x3 with host arrays at both ends, PCIe and
+    # host copies included -- band stream, 2048-row bands, one stream and one host thread
+    # per slot
+    from hydrodem_amd import streaming as St
+    z_host = zd.to_host()
+    streamed = np.empty_like(z_host)
+    with St.BandStream(z_host.shape, band_rows=2048, depth=3, **St.groves_op(3)) as bs:
+        bs.run([z_host, groves_host], streamed)
+        t0 = time.perf_counter()
+        bs.run([z_host, groves_host], streamed)
+        ms = (time.perf_counter() - t0) * 1e3
+    res["groves_x3_host_to_host_stream"] = {
+        "ms": ms, "Mcells_per_s": S * S / ms / 1e3,
+        "note": "host ndarray in, host ndarray out: pinned band buffers, H2D, 3 fused passes, "
+                "D2H; bounded by the host copies (9 B/cell in, 4 B/cell out through PCIe)"}
+    del streamed
     if with_cpu:
-        z_host = zd.to_host()
         res["groves_x3"]["cpu_numpy_oracle"], res["boxmean3_round"]["cpu_scipy_oracle"] = \
             cpu_b(z_host, groves_host)
-        del z_host
-    del groves_host
+    del z_host, groves_host
     ctx.profile(True)
     ctx.profile_reset()
     res["fourier_destripe"] = line(timed(ctx, lambda: B.fourier_destripe_dev(zd, out=scratch), reps))

@@ -16,16 +16,22 @@ of overlap on each side (the operator's reach: 1 for D8 and the 3 x 3 mean, 7 pe
 quadratic pass, 21 for three groves passes; the overlap is recomputed, never
 exchanged).  ``depth`` slots, each with its own context = its own HIP stream, its
 own pinned input / output buffers and device rasters, take the bands round robin:
-slot k queues  H2D -> kernels -> D2H  on its stream and returns; while it runs,
-the host fills the next slot's input buffer and drains the previous one's output.
-The only waits are ``hdem_synchronize`` of the slot about to be reused.  The
-raster's own first / last rows are the band's, so border semantics (untouched
-rings, reflect) are the operator's own.
+slot k fills its input buffer, queues  H2D -> kernels -> D2H  on its stream, waits
+for it and hands the result to the writer.  Every slot is driven by a host thread of
+its own, so the host-side copies -- the largest cost once the kernels take a few
+milliseconds: a 16384^2 float32 raster is 1 GiB each way through ``np.copyto`` --
+overlap with each other and with the other slots' transfers and kernels (NumPy's
+copies, ``ctypes`` calls and ``hdem_synchronize`` all release the GIL).  Caller
+supplied ``read`` / ``write`` callables are serialised with a lock unless told
+otherwise (a GDAL dataset handle is not thread safe), and results are written in band
+order.  The raster's own first / last rows are the band's, so border semantics
+(untouched rings, reflect) are the operator's own.
 
 Not for the sink fill: its dependences are global (`partition.py` splits it).
 """
 
 import ctypes
+import threading
 
 import numpy as np
 
@@ -72,7 +78,6 @@ class _Slot:
         self.dev_out = backend.DeviceRaster.empty((rows, cols), out_dtype, self.ctx)
         self.scratch = [backend.DeviceRaster.empty((rows, cols), dt, self.ctx)
                         for dt in scratch_dtypes]
-        self.pending = None                      # (r0, r1, lo) of the band in flight
 
     def free(self):
         self.ctx.synchronize()
@@ -122,26 +127,36 @@ class BandStream:
     def __exit__(self, *exc):
         self.close()
 
-    def _drain(self, slot, write):
-        if slot.pending is None:
-            return
-        r0, r1, lo = slot.pending
-        slot.ctx.synchronize()
-        write(r0, r1, slot.host_out.array[r0 - lo:r1 - lo])
-        slot.pending = None
-
-    def run(self, sources, sink):
+    def run(self, sources, sink, threads=True, serial_io=None):
         """``sources``: one per input -- an array-like (sliced by rows) or a callable
         ``read(lo, hi, out_view)``; ``sink``: an array-like or ``write(r0, r1, view)``
-        (the view is only valid during the call)."""
-        readers = [s if callable(s) else (lambda lo, hi, out, a=s: np.copyto(out, a[lo:hi]))
-                   for s in sources]
-        write = sink if callable(sink) else \
+        (the view is only valid during the call).  ``threads``: one host thread per slot
+        (else everything on the caller's thread, bands one after the other).
+        ``serial_io``: never run two caller-supplied callables at once (default: yes when
+        any is given; arrays and memmaps are copied concurrently either way).  Results
+        reach ``sink`` in band order."""
+        user_io = any(callable(s) for s in sources) or callable(sink)
+        io_lock = threading.Lock() if (user_io if serial_io is None else serial_io) else None
+
+        def guarded(fn):
+            if io_lock is None:
+                return fn
+
+            def locked(*args):
+                with io_lock:
+                    return fn(*args)
+            return locked
+
+        readers = [guarded(s) if callable(s) else
+                   (lambda lo, hi, out, a=s: np.copyto(out, a[lo:hi])) for s in sources]
+        write = guarded(sink) if callable(sink) else \
             (lambda r0, r1, v, a=sink: a.__setitem__(slice(r0, r1), v))
         lib = self.slots[0].ctx.lib
-        for k, (r0, r1, lo, hi) in enumerate(self.bands):
-            slot = self.slots[k % len(self.slots)]
-            self._drain(slot, write)                  # the slot's previous band
+        turn = threading.Condition()
+        state = {"next": 0, "error": None}
+
+        def band(k, slot):
+            r0, r1, lo, hi = self.bands[k]
             n = hi - lo
             c = slot.ctx
             for read, hbuf, dbuf in zip(readers, slot.host_in, slot.dev_in):
@@ -152,9 +167,42 @@ class BandStream:
                     [_view(d, n) for d in slot.scratch])
             c.check(lib.hdem_memcpy_d2h_async(c.handle, slot.host_out.ptr, slot.dev_out.ptr,
                                               n * self.shape[1] * slot.host_out.array.itemsize))
-            slot.pending = (r0, r1, lo)
-        for k in range(len(self.slots)):              # in band order
-            self._drain(self.slots[(len(self.bands) + k) % len(self.slots)], write)
+            c.synchronize()
+            with turn:                                    # in band order
+                while state["next"] != k and state["error"] is None:
+                    turn.wait()
+            if state["error"] is None:
+                write(r0, r1, slot.host_out.array[r0 - lo:r1 - lo])
+            with turn:
+                state["next"] = k + 1
+                turn.notify_all()
+
+        def worker(index):
+            try:
+                for k in range(index, len(self.bands), len(self.slots)):
+                    if state["error"] is not None:
+                        return
+                    band(k, self.slots[index])
+            except BaseException as exc:                  # pylint: disable=broad-except
+                with turn:
+                    state["error"] = state["error"] or exc
+                    turn.notify_all()
+
+        if threads and len(self.slots) > 1:
+            pool = [threading.Thread(target=worker, args=(i,)) for i in range(len(self.slots))]
+            for t in pool:
+                t.start()
+            for t in pool:
+                t.join()
+        else:
+            for k in range(len(self.bands)):
+                if state["error"] is None:
+                    try:
+                        band(k, self.slots[k % len(self.slots)])
+                    except BaseException as exc:          # pylint: disable=broad-except
+                        state["error"] = exc
+        if state["error"] is not None:
+            raise state["error"]
 
 
 # ---- the operators of the scope table as band operators -----------------------

@@ -137,7 +137,7 @@ def test_groves_class_with_values_other_than_0_and_1_follows_the_reference_algeb
     want = hl * (1 - klass * ((hl > 1.5) * 1)) + smooth
     assert got.dtype == np.float64
     sure = np.abs(hl - 1.5) > 1e-3
-    assert (klass * (hl > 1.5)).sum() > 50 and np.abs(got - want)[sure].max() <= 1e-4
+    assert (klass * (hl > 1.5)).sum() > 10 and np.abs(got - want)[sure].max() <= 1e-4
     # iterated: member by member too
     got3 = hd.GrovesCorrectionsIter(klass, iterations=2).apply(img)
     assert got3.dtype == np.float64 and np.isfinite(got3).all()
