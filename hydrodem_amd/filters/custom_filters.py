@@ -101,7 +101,10 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
     are read at ``apply`` time.  ``partial_results`` is filled only with
     ``keep_partial_results=True`` (it costs an extra quadratic pass)."""
 
-    auto_device = True      # device form == host form for a float32 raster
+    @property
+    def auto_device(self):
+        """Device form == host form for a float32 raster -- with a 0 / 1 class raster."""
+        return self._is_mask(self._params()[0])
 
     def __init__(self, groves_class, keep_partial_results=False):  # pylint: disable=super-init-not-called
         self.partial_results = []

@@ -79,3 +79,33 @@ def test_two_rank_rehearsal_on_one_gpu(tmp_path, built, world, H, W):
     assert got_g.shape == whole.shape and np.abs(got_g - whole).max() <= 1e-4
     assert np.array_equal(np.concatenate([p["boxmean"] for p in parts]),
                           backend.boxmean3_dev(backend.DeviceRaster.from_host(got_g)).to_host())
+
+
+def test_bench_starts_its_own_ranks(built):
+    """`python bench.py --gpus 2` with no launcher around it -- the shape of command the
+    driver issues -- spawns its ranks itself (here both on cuda:0 over gloo:
+    HDEM_REHEARSE=1) and prints rank 0's one JSON line with the per-rank detail."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HDEM_REHEARSE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size",
+                          "2048", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["metric"].endswith("4096x2048 float32 DEM")
+    assert rec["config"]["halo_exchanges"] >= 2 and rec["config"]["tiles"] > 0
+    assert rec["config"]["visits_unchanged"] is not None
+    assert len(rec["per_rank"]["fill_async_ms_per_step"]) == 2
+    assert all(v > 0 for v in rec["per_rank"]["tile_visits_per_step"])
+    # a rank that dies takes the whole run down with a non-zero status
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size",
+                          "-5"], env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
