@@ -13,10 +13,10 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-filters --cpu-sample 0"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench -- $BENCH > "$OUT/bench_under_rocprof.json"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/stats" -o bench -- $BENCH > "$OUT/bench_under_rocprof.json"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o bench -- $BENCH > /dev/null
+    rocprofv3 --output-format csv --pmc $c -d "$OUT/pmc_$c" -o bench -- $BENCH > /dev/null
     python3 "$ROOT/tools/summarize_pmc.py" "$(find "$OUT/pmc_$c" -name '*counter_collection.csv' | head -1)" \
         > "$OUT/${TAG}_bench_pmc_$(echo $c | tr 'A-Z' 'a-z').csv"
 done
@@ -25,7 +25,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     d="$OUT/sq_$(echo $set | cut -d' ' -f2)"
-    rocprofv3 --pmc $set -d "$d" -o fill -- python3 "$ROOT/tools/fill_once.py" 16384 3 > /dev/null 2>&1
+    rocprofv3 --output-format csv --pmc $set -d "$d" -o fill -- python3 "$ROOT/tools/fill_once.py" 16384 3 > /dev/null 2>&1
     python3 "$ROOT/tools/summarize_pmc.py" "$(find "$d" -name '*counter_collection.csv' | head -1)" \
         | grep -E "Kernel_Name|fill_async_kernel<false, 0>" >> "$OUT/${TAG}_fill_pmc_sq.csv"
 done
