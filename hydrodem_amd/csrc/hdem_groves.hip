@@ -145,33 +145,25 @@ __global__ __launch_bounds__(NT) void groves_kernel(const float *__restrict__ im
 }
 
 // ---------------------------------------------------------------------------
-// Streaming form of the same arithmetic (ws = 3, 9, 15: the production window).  One WAVE
-// owns a window of 256 columns x (128 + 2p) rows and walks down it once; lane l holds columns
-// 4l..4l+3 as one float4 (a wave-level load is 1 KiB of one raster row, rows prefetched three
-// ahead).  Vertical first, in registers, then horizontal through LDS:
-//   * vertical: the last `ws` rows of d = w - c0 stay in a register ring (slot = row mod ws,
-//     static after unrolling by ws) and three moments per column slide down with every row,
-//         M0' = M0 - old + new,  M1' = M1 - (M0 - old) + (n-1) new,
-//         M2' = M2 - 2 M1 + (M0 - old) + (n-1)^2 new          (k = 0 oldest .. n-1 newest),
-//     7 packed operations per column pair; C0 = M0 is the column's box sum and
-//     Y2 = M2 + 2 v0 M1 + v0^2 M0 its v^2-weighted sum (v_k = k + v0);
-//   * horizontal: K = a (xx^2 + yy^2) + b, so
-//         out = sum_i [ (a v_i^2 + b) C0(x+i) + a Y2(x+i) ]
-//     -- C0 and Y2 of the row go through a wave-private LDS row (two slots, no workgroup
-//     barrier), every lane reads the 20 values around its columns as aligned ds_read_b128,
-//     and the weighted sum of C0 slides from column to column as three moments again while
-//     the box sum of Y2 rides along in the other half of the packed registers.
-// ~165 vector operations per lane-row of 4 cells (round 1: a ring of `ws` accumulators per
-// column, every input row scattered to all of them: 263).  The 8 columns on each side of the
-// window are context only (240 outputs per 256 columns: 1.07 x the loads, no halo lanes);
-// rows overlap by 2p (1.11 x at ws = 15).  The centre value of a finished output row is in
-// the register ring (row i - p): no raw-row buffer.
+// Streaming form of the same arithmetic (used for ws <= 15).  One WAVE owns a
+// 256-column x 128-row strip and walks down its input rows once:
+//   * lane l holds columns 4l..4l+3 as one float4 (a wave-level load is 1 KiB of
+//     one raster row); lanes 0..2p-1 also fetch one halo column each; rows are
+//     prefetched three ahead so ~3 KiB per wave are always in flight;
+//   * the row (as d = w - c0) goes through a wave-private LDS row buffer (two
+//     alternating slots, no workgroup barrier) from which each lane reads the
+//     4+2p values around its columns as aligned ds_read_b128;
+//   * the row sums R0/R2 feed a ring of `ws` vertical accumulators per column held
+//     in registers (slot = output row mod ws, static after unrolling by ws): the
+//     output row that receives its last term is finished, blended and stored.
+// HBM reads are the raster once plus (128+2p)/128 row overlap (1.11x at ws = 15)
+// instead of the 1.75x of the tiled kernel; no tile is staged twice.
 // ---------------------------------------------------------------------------
-constexpr int SW_COLS = 256;     // window width  (cells) = 64 lanes x 4
-constexpr int SW_HALO = 8;       // context columns on each side (>= p, a multiple of 4)
-constexpr int SW_OUT = SW_COLS - 2 * SW_HALO;
+constexpr int SW_COLS = 256;     // strip width  (cells) = 64 lanes x 4
 constexpr int SR_ROWS = 128;     // strip height (output rows)
 
+// (at least 3 waves per SIMD: ws = 15 then fits 168 registers with 5 of them spilled,
+// and runs 6 % faster than at 183 registers and 2 waves)
 template <int WS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void groves_stream_kernel(const float *__restrict__ img,
                                                           const uint8_t *__restrict__ groves,
@@ -180,44 +172,59 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
                                                           quad_coef cf, float *__restrict__ out)
 {
     constexpr int P = WS / 2;
-    static_assert(P <= SW_HALO - 1, "context columns too few for the window");
+    constexpr int PADL = (P + 3) / 4 * 4;                 // interior starts 16-byte aligned
+    constexpr int OFF = PADL - P;                         // first needed float, from the aligned read
+    constexpr int NRD = (OFF + 4 + 2 * P + 3) / 4;        // ds_read_b128 per lane per row
+    constexpr int RB = (PADL + SW_COLS + P + 3) / 4 * 4 + 4;   // row buffer (floats)
     constexpr int PF = 3;                                 // rows in flight (divides the unroll)
     static_assert(WS % PF == 0 || WS < PF, "prefetch ring must divide the unroll");
-    constexpr int OFF = SW_HALO - P;                      // first tap of output 0 in the 20 read
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) float xch[4][2][2][SW_COLS];   // wave, slot, C0 / Y2
+    constexpr int NSLOT = 8;                              // >= p + 1 rows of history (ws <= 15)
+    static_assert(P + 1 <= NSLOT, "row ring too short");
+    __shared__ __attribute__((aligned(16))) float rows[4][NSLOT][RB];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip >= nstrips) return;
     const int sy = strip / strips_x, sx = strip - sy * strips_x;
-    const int xs = sx * SW_OUT - SW_HALO, y0 = sy * SR_ROWS;
-    const int x = xs + 4 * lane;                          // (negative in the first window)
-    const bool vec_in = x >= 0 && x + 4 <= W;
-    const bool mine = lane >= SW_HALO / 4 && lane < (SW_COLS - SW_HALO) / 4 && x < W;
-    const bool vec_out = mine && x + 4 <= W;
+    const int x0 = sx * SW_COLS, y0 = sy * SR_ROWS;
+    const int x = x0 + 4 * lane;
+    float *rb = &rows[wave][0][0];
+    const bool vec_ok = x + 4 <= W;
 
-    float c0 = img[(size_t)min(y0 + SR_ROWS / 2, H - 1) * W + min(max(xs + SW_COLS / 2, 0), W - 1)];
+    float c0 = img[(size_t)min(y0 + SR_ROWS / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
     if (!(fabsf(c0) < HDEM_INF)) c0 = 0.0f;
 
-    auto load_row = [&](int i, hdem_f4 &v) {
+    // halo column of this lane (lanes 0..2p-1): left halo x0-p+lane, right x0+256+(lane-p)
+    const bool has_halo = lane < 2 * P;
+    const int hx = min(max(lane < P ? x0 - P + lane : x0 + SW_COLS + lane - P, 0), W - 1);
+    const int hidx = lane < P ? OFF + lane : PADL + SW_COLS + lane - P;
+
+    auto load_row = [&](int i, hdem_f4 &v, float &hv) {
         const int y = min(max(y0 - P + i, 0), H - 1);
         const float *row = img + (size_t)y * W;
-        if (vec_in) {
+        if (x + 4 <= W) {
             v = hdem_ld4u(row + x);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = row[min(max(x + k, 0), W - 1)];
+            for (int k = 0; k < 4; ++k) v[k] = row[min(x + k, W - 1)];
         }
+        hv = has_halo ? row[hx] : 0.0f;
     };
+
+    // accumulators as float2 pairs: the vertical update is v_pk_add + v_pk_fma
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[WS][2];
+#pragma unroll
+    for (int j = 0; j < WS; ++j) { acc[j][0] = (f2){0.0f, 0.0f}; acc[j][1] = (f2){0.0f, 0.0f}; }
+
     // groves bytes of the output row that completes at step i (row y0 + i - 2p), fetched
     // PF steps ahead like the image rows: nothing in the loop waits on a fresh load
     auto load_mask = [&](int i) -> unsigned {
         const int y = y0 + i - 2 * P;
         unsigned g = 0;
-        if (groves && mine && y >= 0 && y < H) {
+        if (groves && y >= 0 && y < H && x < W) {
             const size_t gi = (size_t)y * W + x;
-            if (vec_out && (gi & 3) == 0) g = *reinterpret_cast<const unsigned *>(groves + gi);
+            if (vec_ok && (gi & 3) == 0) g = *reinterpret_cast<const unsigned *>(groves + gi);
             else
                 for (int k = 0; k < 4; ++k)
                     if (x + k < W) g |= (unsigned)groves[gi + k] << (8 * k);
@@ -225,110 +232,105 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
         return g;
     };
 
-    f2 hist[WS][2], m0[2], m1[2], m2[2];
-#pragma unroll
-    for (int j = 0; j < WS; ++j) { hist[j][0] = (f2){0.0f, 0.0f}; hist[j][1] = (f2){0.0f, 0.0f}; }
-#pragma unroll
-    for (int p2 = 0; p2 < 2; ++p2) { m0[p2] = m1[p2] = m2[p2] = (f2){0.0f, 0.0f}; }
-
     hdem_f4 pre[PF];
+    float preh[PF];
     unsigned preg[PF];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) { load_row(k, pre[k]); preg[k] = load_mask(k); }
-
-    constexpr float V0 = 1.0f - WS / 2.0f, N1 = (float)(WS - 1), N1SQ = (float)((WS - 1) * (WS - 1));
-    constexpr float NN = (float)WS, N2 = (float)(WS * WS - 2 * WS);
-    const float a0 = cf.a * (V0 * V0), a1 = cf.a * (2.0f * V0);
-    const float b = cf.cy[0] - a0;                        // cy[k] = a v_k^2 + b, v_0 = V0
-    const f2 cm1 = {-1.0f, -1.0f}, c2v = {2.0f * V0, 2.0f * V0}, cvv = {V0 * V0, V0 * V0};
-    const f2 cn1 = {N1, N1}, cn1sq = {N1SQ, N1SQ}, cm2 = {-2.0f, -2.0f};
-    float *xw = &xch[wave][0][0][0];
+    for (int k = 0; k < PF; ++k) { load_row(k, pre[k], preh[k]); preg[k] = load_mask(k); }
 
     constexpr int NROWS = SR_ROWS + 2 * P;
     for (int base = 0; base < NROWS; base += WS) {
 #pragma unroll
         for (int u = 0; u < WS; ++u) {
             const int i = base + u;
+            // ---- row i: registers -> LDS row slot, next prefetch ------------------
+            float *slot = rb + (i & (NSLOT - 1)) * RB;      // raw image row i
             const hdem_f4 v = pre[u % PF];
+            const float hv = preh[u % PF];
             const unsigned g4 = preg[u % PF];
-            load_row(i + PF, pre[u % PF]);
+            *reinterpret_cast<hdem_f4 *>(slot + PADL + 4 * lane) = v;
+            if (has_halo) slot[hidx] = hv;
+            load_row(i + PF, pre[u % PF], preh[u % PF]);
             preg[u % PF] = load_mask(i + PF);
-            // ---- vertical: the column moments slide down by one row ----------------------
-            f2 c0v[2], y2v[2];
-#pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) {
-                const f2 nw = (f2){v[2 * p2], v[2 * p2 + 1]} - (f2){c0, c0};
-                const f2 t = m0[p2] - hist[u][p2];                    // M0 - old
-                m2[p2] = __builtin_elementwise_fma(cn1sq, nw,
-                                                   __builtin_elementwise_fma(cm2, m1[p2], m2[p2]) + t);
-                m1[p2] = __builtin_elementwise_fma(cn1, nw, m1[p2] - t);
-                m0[p2] = t + nw;
-                hist[u][p2] = nw;
-                c0v[p2] = m0[p2];
-                y2v[p2] = __builtin_elementwise_fma(
-                    c2v, m1[p2], __builtin_elementwise_fma(cvv, m0[p2], m2[p2]));
-            }
-            (void)cm1;
-            const int oy = i - 2 * P, y = y0 + oy;            // the output row that is complete
-            if (oy < 0 || oy >= SR_ROWS || y >= H) continue;  // (uniform)
-            // ---- horizontal: C0 and Y2 of this row through the wave's LDS row --------------
-            float *slot = xw + (i & 1) * (2 * SW_COLS);
-            *reinterpret_cast<hdem_f4 *>(slot + 4 * lane) =
-                (hdem_f4){c0v[0][0], c0v[0][1], c0v[1][0], c0v[1][1]};
-            *reinterpret_cast<hdem_f4 *>(slot + SW_COLS + 4 * lane) =
-                (hdem_f4){y2v[0][0], y2v[0][1], y2v[1][0], y2v[1][1]};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // 20 values of each around my columns: columns x - 8 .. x + 11 (lanes at the window's
-            // sides read clamped addresses; they produce no output)
-            f2 q[20];                                         // (C0, Y2) pairs
-            const int lo = min(max(lane - 2, 0), 64 - 5) * 4;
+            // ---- 4 + 2p values around my columns ------------------------------------
+            float d[NRD * 4];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const hdem_f4 qa = *reinterpret_cast<const hdem_f4 *>(slot + lo + 4 * k);
-                const hdem_f4 qb = *reinterpret_cast<const hdem_f4 *>(slot + SW_COLS + lo + 4 * k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) q[4 * k + e] = (f2){qa[e], qb[e]};
+            for (int k = 0; k < NRD; ++k) {
+                const hdem_f4 q = *reinterpret_cast<const hdem_f4 *>(slot + 4 * lane + 4 * k);
+                d[4 * k] = q[0] - c0; d[4 * k + 1] = q[1] - c0;
+                d[4 * k + 2] = q[2] - c0; d[4 * k + 3] = q[3] - c0;
             }
-            // moments of C0 over the 15 taps of output 0 (the box sum of Y2 rides in .y of s0)
-            f2 s0 = {0.0f, 0.0f};
-            float h1 = 0.0f, h2 = 0.0f;
+            // ---- row sums, then into the ring of vertical accumulators --------------
+            // Moments instead of four 15-tap sums: with v_k = k + v0 the weighted row sum is
+            // sum v_k^2 d = M2 + 2 v0 M1 + v0^2 M0 (M_i = sum k^i d), and the three moments
+            // slide from one output column to the next in 7 operations
+            //   M0' = M0 - a + e,  M1' = M1 + n e - M0',  M2' = M2 - 2 M1 + (n^2 - 2n) e + M0'
+            // (a leaves the window, e enters): 78 operations per lane-row instead of 120.
+            // The offsets d = w - c0 are a few metres, M2 ~ 1e5: 1e-5 m after the a = 3e-4.
+            float r0[4], r2[4];
+            {
+                constexpr float V0 = 1.0f - WS / 2.0f, NN = (float)WS, N2 = (float)(WS * WS - 2 * WS);
+                const float a0 = cf.a * (V0 * V0), a1 = cf.a * (2.0f * V0);
+                float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
-            for (int k = 0; k < WS; ++k) {
-                s0 += q[OFF + k];
-                h1 = fmaf((float)k, q[OFF + k][0], h1);
-                h2 = fmaf((float)(k * k), q[OFF + k][0], h2);
-            }
-            float acc[4];
+                for (int k = 0; k < WS; ++k) {
+                    const float x = d[OFF + k];
+                    m0 += x;
+                    m1 = fmaf((float)k, x, m1);
+                    m2 = fmaf((float)(k * k), x, m2);
+                }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                // a sum v^2 C0 + b sum C0 + a sum Y2
-                acc[o] = fmaf(cf.a, s0[1], fmaf(b + a0, s0[0], fmaf(a1, h1, cf.a * h2)));
-                if (o < 3) {
-                    const f2 s0n = s0 - q[OFF + o] + q[OFF + o + WS];
-                    const float en = q[OFF + o + WS][0];
-                    const float h1n = fmaf(NN, en, h1) - s0n[0];
-                    h2 = fmaf(N2, en, fmaf(-2.0f, h1, h2)) + s0n[0];
-                    h1 = h1n;
-                    s0 = s0n;
+                for (int o = 0; o < 4; ++o) {
+                    r0[o] = m0;
+                    r2[o] = fmaf(a0, m0, fmaf(a1, m1, cf.a * m2));
+                    if (o < 3) {
+                        const float lv = d[OFF + o], en = d[OFF + o + WS];
+                        const float m0n = m0 - lv + en;
+                        const float m1n = fmaf(NN, en, m1) - m0n;
+                        m2 = fmaf(N2, en, fmaf(-2.0f, m1, m2)) + m0n;
+                        m1 = m1n;
+                        m0 = m0n;
+                    }
                 }
             }
-            // ---- blend and store: the centre row (input row i - p) is in the ring -------------
-            if (mine) {
-                const int cu = ((u - P) % WS + WS) % WS;
-                const float dv[4] = {hist[cu][0][0], hist[cu][0][1], hist[cu][1][0], hist[cu][1][1]};
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const f2 r = {r0[2 * p2], r0[2 * p2 + 1]}, t = {r2[2 * p2], r2[2 * p2 + 1]};
+                // (all the adds, then all the fmas: written as add-then-fma per slot the
+                // compiler reuses one temporary, and a packed fma that consumes the packed
+                // add just before it needs a wait state -- 30 s_nop per row)
+#pragma unroll
+                for (int j = 0; j < WS; ++j) acc[j][p2] += t;
+#pragma unroll
+                for (int j = 0; j < WS; ++j) {
+                    // output row (i - j) sits in slot (u - j) mod WS and takes weight cy[j]
+                    const int sl = ((u - j) % WS + WS) % WS;
+                    const f2 cy = {cf.cy[j], cf.cy[j]};
+                    acc[sl][p2] = __builtin_elementwise_fma(cy, r, acc[sl][p2]);
+                }
+            }
+            // ---- output row i - 2p is complete: blend and store ------------------------
+            const int done = (u + 1) % WS;            // slot of output row i - (WS - 1)
+            const int oy = i - 2 * P, y = y0 + oy;
+            if (oy >= 0 && oy < SR_ROWS && y < H && x < W) {
                 const size_t gi = (size_t)y * W + x;
                 float o4[4];
+                // the centre row of this output (input row i - p) is still in the ring, raw
+                const hdem_f4 wq = *reinterpret_cast<const hdem_f4 *>(
+                    rb + ((i - P) & (NSLOT - 1)) * RB + PADL + 4 * lane);
+                const float wv[4] = {wq[0], wq[1], wq[2], wq[3]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float smooth = c0 + acc[k], wv = c0 + dv[k];
+                    const float smooth = c0 + acc[done][k >> 1][k & 1];
                     const int xx = x + k;
                     const bool ring = y < P || y >= H - P || xx < P || xx >= W - P;
                     float o;
                     if (ring) {
-                        o = wv;
+                        o = wv[k];
                     } else if (groves) {
-                        const float hl = wv - smooth;
+                        const float hl = wv[k] - smooth;
                         const bool m = ((g4 >> (8 * k)) & 0xffu) != 0 && hl > thr;
                         o = m ? smooth : hl + smooth;
                     } else {
@@ -336,15 +338,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
                     }
                     o4[k] = o;
                 }
-                if (vec_out) {
-                    hdem_f4 qo = {o4[0], o4[1], o4[2], o4[3]};
-                    hdem_st4u(out + gi, qo);
+                if (vec_ok) {
+                    hdem_f4 q = {o4[0], o4[1], o4[2], o4[3]};
+                    hdem_st4u(out + gi, q);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (x + k < W) out[gi + k] = o4[k];
                 }
             }
+            acc[done][0] = (f2){0.0f, 0.0f};
+            acc[done][1] = (f2){0.0f, 0.0f};
         }
     }
 }
@@ -373,7 +377,7 @@ void launch_ws(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, in
                float thr, const quad_coef &cf, float *out)
 {
     if constexpr (WS == 15 || WS == 9 || WS == 3) {      // streaming form (prefetch ring | ws)
-        const int sx = (W + SW_OUT - 1) / SW_OUT, sy = (H + SR_ROWS - 1) / SR_ROWS;
+        const int sx = (W + SW_COLS - 1) / SW_COLS, sy = (H + SR_ROWS - 1) / SR_ROWS;
         const int n = sx * sy;
         hipLaunchKernelGGL(groves_stream_kernel<WS>, dim3((n + 3) / 4), dim3(NT), 0, ctx->stream,
                            img, groves, H, W, thr, sx, n, cf, out);
