@@ -417,7 +417,8 @@ def main():
         mine = torch.tensor([kt["ms"], kc["ms"] + kb["ms"], kr["ms"], ki["ms"],
                              float(sum(s["tile_visits"] for s in step_stats)),
                              float(sum(s["visits_unchanged"] for s in step_stats)),
-                             float(last["tiles"] or 0), float(last["exchanges"])],
+                             float(last["tiles"] or 0), float(last["exchanges"]),
+                             float(sum(s_["async_fallbacks"] for s_ in step_stats))],
                             dtype=torch.float64)
         parts = [torch.zeros_like(mine) for _ in range(world)]
         if rehearse:
@@ -434,7 +435,10 @@ def main():
                     "tile_visits_per_step": [float(p[4]) / k for p in parts],
                     "visits_unchanged_per_step": [float(p[5]) / k for p in parts],
                     "tiles": [int(p[6]) for p in parts],
-                    "exchanges": [int(p[7]) for p in parts]}
+                    "exchanges": [int(p[7]) for p in parts],
+                    # local solves finished by the round driver because the persistent
+                    # launch did not get the whole GPU (0 on a node with one rank per GPU)
+                    "async_fallbacks": [int(p[8]) for p in parts]}
 
     if rank == 0:
         copy_gbs = B.copy_rate(ctx)

@@ -194,3 +194,28 @@ def test_band_ranges_cover_the_raster_with_halos():
     assert S.band_ranges(5, 8, 21) == [(0, 5, 0, 5)]
     with pytest.raises(ValueError):
         S.band_ranges(5, 0, 1)
+
+
+def test_bench_reports_pmc_traffic_only_for_the_kernel_it_was_taken_from(tmp_path, monkeypatch):
+    """`roofline.traffic` is a committed rocprofv3 --pmc record stamped with the hash of the
+    kernel's source; a record of another build, or of another size, is not reported."""
+    import json
+    import bench
+    rec = tmp_path / "traffic.json"
+    monkeypatch.setattr(bench, "TRAFFIC_RECORD", str(rec))
+    assert bench.profiled_traffic(16384)[0] is None                    # no record
+    good = {"kernel_hash": bench.kernel_source_hash(), "size": 16384, "bytes_per_launch": 1.5e10,
+            "head": "abc1234", "source": "x"}
+    rec.write_text(json.dumps(good))
+    value, meta = bench.profiled_traffic(16384)
+    assert value == 1.5e10 and meta["traffic_profile_head"] == "abc1234"
+    assert bench.profiled_traffic(4096)[0] is None
+    rec.write_text(json.dumps(dict(good, kernel_hash="0" * 16)))
+    value, meta = bench.profiled_traffic(16384)
+    assert value is None and "another build" in meta["traffic_note"]
+    # the committed record belongs to the committed kernel
+    monkeypatch.undo()
+    if os.path.exists(bench.TRAFFIC_RECORD):
+        committed = json.load(open(bench.TRAFFIC_RECORD))
+        assert committed["kernel_hash"] == bench.kernel_source_hash(), \
+            "hdem_sinkfill.hip changed after the PMC passes: re-run tools/profile_round.sh"
