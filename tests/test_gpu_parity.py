@@ -703,3 +703,62 @@ def test_degenerate_rasters():
     assert not hd.D8FlowDirection().apply(z).any()
     z = np.full((70, 70), np.nan, np.float32)             # all nodata
     assert np.isnan(hd.SinkFill().apply(z)).all()
+
+
+# --------------------------------------------------------------------------
+# flat tiles: visits that read the halo ring only (hdem_sinkfill.hip, flat_visit)
+# --------------------------------------------------------------------------
+def _crater(n, rim, passes, island_nan=False, seed=5):
+    """A noisy bowl n x n inside a rim at `rim` metres with gaps in the rim at the given
+    (position along the north side, elevation) pairs: the lake settles at the lowest gap,
+    and the fill finds the gaps one after the other -- its level drops in stages."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:n, 0:n]
+    r = np.hypot(y - n / 2, x - n / 2) / (n / 2)
+    z = (20.0 + 10.0 * np.clip(r, 0, 1) ** 2 + rng.normal(0, 0.3, (n, n))).astype(np.float32)
+    ring = (r > 0.86) & (r < 0.93)
+    z[ring] = rim
+    z[r >= 0.93] = 5.0 - 3.0 * (r[r >= 0.93] - 0.93)               # falls away outside
+    for pos, level in passes:                                       # gaps through the rim
+        cx = int(n / 2 + (pos - 0.5) * n * 0.6)
+        z[:n // 2, cx - 1:cx + 2] = np.minimum(z[:n // 2, cx - 1:cx + 2], level)
+    if island_nan:
+        z[n // 2 - 3:n // 2 + 3, n // 2 + 40:n // 2 + 46] = np.nan   # nodata inside the lake
+    return z
+
+
+@pytest.mark.parametrize("passes,island", [
+    (((0.5, 33.0),), False),                      # one gap: one level
+    (((0.2, 36.0), (0.5, 34.0), (0.8, 31.5)), False),   # found one after the other
+    (((0.5, 33.0),), True),                       # nodata in the bowl: an outlet, the lake drains
+    (((0.5, 24.0),), False),                      # a gap below the bowl's slopes: the lake
+])                                                # shrinks to the bottom, tiles leave the flat path
+def test_sinkfill_lakes_take_the_flat_path_and_stay_exact(passes, island):
+    z = _crater(1500, 40.0, passes, island)
+    zd = backend.DeviceRaster.from_host(z)
+    wd, codes, st = backend.sinkfill_d8_dev(zd)
+    want = c_oracle.sinkfill_pflood(z)
+    assert st["converged"] and st["async_timed_out"] == 0
+    assert np.array_equal(wd.to_host(), want, equal_nan=True)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    if not island:
+        assert st["visits_flat"] > 0              # the lake's tiles did take the short path
+        assert np.nanmax(want - z) > 3.0          # and there is a lake
+    # a second fill into the same output (stale interiors of flat tiles from the first
+    # call must not leak): same bits
+    wd2, st2 = backend.sinkfill_dev(zd, out=wd)
+    assert np.array_equal(wd2.to_host(), want, equal_nan=True)
+    zd.free()
+    wd.free()
+    codes.free()
+
+
+def test_flat_path_with_the_coarse_start(monkeypatch):
+    """The same lake above the size from which the fill starts from a coarse solve
+    (threshold lowered so that the test stays small)."""
+    monkeypatch.setenv("HDEM_COARSE_MIN_CELLS", "1000000")
+    z = _crater(1800, 40.0, ((0.3, 35.0), (0.7, 32.0)))
+    wd, st = backend.sinkfill_dev(backend.DeviceRaster.from_host(z))
+    assert np.array_equal(wd.to_host(), c_oracle.sinkfill_pflood(z))
+    assert st["visits_flat"] > 0
+    wd.free()
