@@ -51,45 +51,45 @@ for j, (rlo, rhi) in enumerate(bands):
 node_z = z[node_r, node_c]
 
 def band_dp(zz, bands, node_r, node_c):
-    """Horizontal bands of raster zz: forward DPs between consecutive nodes of every band.
-    Returns (edge[j][i] between node i and i+1, U-contribution arrays costA, costB per band as
-    dicts row-range -> arrays)."""
+    """Horizontal bands of raster zz: forward recurrences between consecutive nodes of every
+    band, all bands at once (vectorised over bands, a Python loop over the columns).
+    Returns (edge[j][i] between node i and i+1, [(costA, costB)] per band)."""
     nb = len(bands)
-    edges = np.full((nb, nb - 1), np.inf, dtype=np.float32)
-    costs = []
-    for j, (rlo, rhi) in enumerate(bands):
-        strip = zz[rlo:rhi + 1]                              # k x W
-        k = strip.shape[0]
-        ca = np.full(strip.shape, np.inf, dtype=np.float32)  # cost from the node on the left
-        cb = np.full(strip.shape, np.inf, dtype=np.float32)  # cost from the node on the right
-        rr = node_r[j] - rlo; cc = node_c[j]
-        inf_row = np.full((1,), np.inf, dtype=np.float32)
-        # left -> right: one pass over the columns; a node restarts the recurrence at its cell
-        prev = np.full(k, np.inf, dtype=np.float32)
-        nxt = 0
-        for c in range(strip.shape[1]):
-            m = np.minimum(np.minimum(np.concatenate((inf_row, prev[:-1])), prev),
-                           np.concatenate((prev[1:], inf_row)))
-            cur = np.maximum(strip[:, c], m)
-            if nxt < nb and c == cc[nxt]:
-                if nxt > 0:
-                    edges[j, nxt - 1] = cur[rr[nxt]]         # reached the next node
-                cur = np.full(k, np.inf, dtype=np.float32); cur[rr[nxt]] = strip[rr[nxt], c]
-                nxt += 1
-            ca[:, c] = cur
+    k = max(hi - lo + 1 for lo, hi in bands)
+    wd = zz.shape[1]
+    strips = np.full((nb, k, wd), np.inf, dtype=np.float32)
+    for j, (lo, hi) in enumerate(bands):
+        strips[j, :hi - lo + 1] = zz[lo:hi + 1]
+    rr = node_r - np.array([lo for lo, _ in bands])[:, None]            # node rows inside the band
+    is_node = np.zeros((nb, wd), dtype=np.int64) - 1                     # node index at (band, col)
+    for j in range(nb):
+        is_node[j, node_c[j]] = np.arange(node_c.shape[1])
+    edges = np.full((nb, node_c.shape[1] - 1), np.inf, dtype=np.float32)
+    ca = np.full((nb, k, wd), np.inf, dtype=np.float32)
+    cb = np.full((nb, k, wd), np.inf, dtype=np.float32)
+    inf_col = np.full((nb, 1), np.inf, dtype=np.float32)
+    ar = np.arange(nb)
+
+    def sweep(cols, out, record):
+        prev = np.full((nb, k), np.inf, dtype=np.float32)
+        for c in cols:
+            m = np.minimum(np.minimum(np.concatenate((inf_col, prev[:, :-1]), axis=1), prev),
+                           np.concatenate((prev[:, 1:], inf_col), axis=1))
+            cur = np.maximum(strips[:, :, c], m)
+            hit = is_node[:, c] >= 0
+            if hit.any():
+                jj = ar[hit]; ii = is_node[hit, c]; r = rr[jj, ii]
+                if record:
+                    ok = ii > 0
+                    edges[jj[ok], ii[ok] - 1] = cur[jj[ok], r[ok]]       # reached the next node
+                cur[jj] = np.inf
+                cur[jj, r] = strips[jj, r, c]                             # restart at the node
+            out[:, :, c] = cur
             prev = cur
-        prev = np.full(k, np.inf, dtype=np.float32)
-        nxt = nb - 1
-        for c in range(strip.shape[1] - 1, -1, -1):
-            m = np.minimum(np.minimum(np.concatenate((inf_row, prev[:-1])), prev),
-                           np.concatenate((prev[1:], inf_row)))
-            cur = np.maximum(strip[:, c], m)
-            if nxt >= 0 and c == cc[nxt]:
-                cur = np.full(k, np.inf, dtype=np.float32); cur[rr[nxt]] = strip[rr[nxt], c]
-                nxt -= 1
-            cb[:, c] = cur
-            prev = cur
-        costs.append((ca, cb))
+
+    sweep(range(wd), ca, True)
+    sweep(range(wd - 1, -1, -1), cb, False)
+    costs = [(ca[j, :hi - lo + 1], cb[j, :hi - lo + 1]) for j, (lo, hi) in enumerate(bands)]
     return edges, costs
 
 eh, costs_h = band_dp(z, bands, node_r, node_c)
