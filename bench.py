@@ -418,7 +418,8 @@ def main():
                              float(sum(s["tile_visits"] for s in step_stats)),
                              float(sum(s["visits_unchanged"] for s in step_stats)),
                              float(last["tiles"] or 0), float(last["exchanges"]),
-                             float(sum(s_["async_fallbacks"] for s_ in step_stats))],
+                             float(sum(s_["async_fallbacks"] for s_ in step_stats)),
+                             float(sum(s_["shared_gpu_solves"] for s_ in step_stats))],
                             dtype=torch.float64)
         parts = [torch.zeros_like(mine) for _ in range(world)]
         if rehearse:
@@ -436,9 +437,11 @@ def main():
                     "visits_unchanged_per_step": [float(p[5]) / k for p in parts],
                     "tiles": [int(p[6]) for p in parts],
                     "exchanges": [int(p[7]) for p in parts],
-                    # local solves finished by the round driver because the persistent
-                    # launch did not get the whole GPU (0 on a node with one rank per GPU)
-                    "async_fallbacks": [int(p[8]) for p in parts]}
+                    # local solves finished by the round driver (budget), and solves whose
+                    # persistent launch shared the GPU with another process (0 / 0 on a node
+                    # with one rank per GPU)
+                    "async_fallbacks": [int(p[8]) for p in parts],
+                    "shared_gpu_solves": [int(p[9]) for p in parts]}
 
     if rank == 0:
         copy_gbs = B.copy_rate(ctx)

@@ -50,7 +50,8 @@ class FillStats(ctypes.Structure):
                 ("visits_flat", ctypes.c_int32), ("async_timed_out", ctypes.c_int32),
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
                 ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64),
-                ("pending", ctypes.c_int64)]
+                ("pending", ctypes.c_int64), ("partial_residency", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

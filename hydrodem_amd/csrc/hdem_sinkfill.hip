@@ -893,14 +893,20 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
     __shared__ float T[WN * TS];
     const int G = gridDim.x, b = blockIdx.x;
     const long long t_begin = wall_clock64();
-    // Residency census.  The schedule below needs every workgroup running at once
-    // (a tile is only ever relaxed by its owner).  A grid of 8 single-wave workgroups
-    // per CU is resident on an otherwise idle MI355X, but not when the GPU is shared:
-    // if the others do not show up within 200 us, give up here -- the host then runs
-    // the round-synchronous driver, which needs no co-residency.
+    // Residency census.  The launch is sized so that every workgroup is resident at once on
+    // an otherwise idle MI355X (8 single-wave workgroups per CU) and they start together.  When
+    // the GPU is shared -- another rank's launch, RCCL's kernels -- some of them are not: the
+    // others wait 200 us for them and then start without them.  Nothing depends on an owner
+    // being there: its queued tiles are stolen by workgroups that have run out of their own,
+    // the drain test counts tiles, not workgroups, and a workgroup that is scheduled late finds
+    // nothing queued and leaves.  (Round 1 gave up here and let the host fall back to the
+    // round-synchronous driver, 2-20 x slower; error[3] only records that it happened.)
     if (threadIdx.x == 0) atomicAdd(error + 1, 1);
     while (ld_relaxed(error + 1) < G && ld_relaxed(error) == 0) {
-        if (wall_clock64() - t_begin > 20000) { atomicExch(error, 2); break; }
+        if (wall_clock64() - t_begin > 20000) {
+            if (threadIdx.x == 0) atomicExch(error + 3, 1);
+            break;
+        }
         __builtin_amdgcn_s_sleep(8);
     }
     if (ld_relaxed(error) != 0) return;
@@ -1419,6 +1425,9 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     HDEM_HIP_CHECK(hipMemcpyAsync(hs, ws.stats, stat_words * sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, st));
     HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
+    int partial_residency = 0;
+    HDEM_HIP_CHECK(hipMemcpyAsync(&partial_residency, ws.error + 3, sizeof(int),
+                                  hipMemcpyDeviceToHost, st));
     HDEM_HIP_CHECK(hipStreamSynchronize(st));
     unsigned long long tot[STAT_WORDS] = {};
     for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
@@ -1448,6 +1457,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         stats->tile_w = FT;
         stats->visits_flat = (int32_t)tot[STAT_FLAT];
         stats->async_timed_out = async_error;
+        stats->partial_residency = partial_residency;
+        stats->reserved = 0;
         stats->iterations = (int64_t)tot[1];
         stats->visits_unchanged = (int64_t)tot[2];
         stats->visits_requeued = (int64_t)tot[3];

@@ -448,9 +448,10 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     a ready communicator instead (:class:`DistComm`, or a :class:`ThreadWorld` rank).
     ``info``: tile visits (``unchanged`` of them found nothing to lower), exchanges,
     verifying passes, ``solves`` -- (phase, tile visits) of every local solve, in order --
-    and ``async_fallbacks``: local solves whose persistent launch gave up (the GPU was
-    shared, its workgroups were not co-resident) and were finished by the slower round
-    driver."""
+    ``async_fallbacks``: local solves whose persistent launch ran out of its wall-clock
+    budget and were finished by the round driver, and ``shared_gpu_solves``: solves whose
+    launch did not get all its workgroups resident at once (another process on the GPU) and
+    ran with those it got."""
     import torch
 
     top, bottom = rank > 0, rank < world - 1
@@ -466,7 +467,7 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         # 8192 x 1024 cells and 1.6 ms, and 32 x 32 blocks would cost more in the fine
         # solve than they save here: 16.1 against 15.4 ms predicted)
         coarse_block = COARSE_BLOCK
-    tally = {"tile_visits": 0, "unchanged": 0, "solves": [], "fallbacks": 0}
+    tally = {"tile_visits": 0, "unchanged": 0, "solves": [], "fallbacks": 0, "shared": 0}
 
     def solve(phase, fill_flags, **kw):
         v, lowered, pending = solver.fill(z_local, w, eps, fill_flags, **kw)
@@ -475,6 +476,7 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         tally["unchanged"] += int(st.get("visits_unchanged", 0))
         tally["solves"].append((phase, int(v)))
         tally["fallbacks"] += int(bool(st.get("async_timed_out", 0)))
+        tally["shared"] += int(bool(st.get("partial_residency", 0)))
         return lowered, pending
 
     keep = None
@@ -513,7 +515,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         solve("verify", backend.FILL_WARM | backend.FILL_SYNC_ONLY, d8=d8_out)
     return w, {"tile_visits": tally["tile_visits"], "visits_unchanged": tally["unchanged"],
                "exchanges": exchanges, "verifications": verifications,
-               "solves": tally["solves"], "async_fallbacks": tally["fallbacks"]}
+               "solves": tally["solves"], "async_fallbacks": tally["fallbacks"],
+               "shared_gpu_solves": tally["shared"]}
 
 
 def d8_distributed(w_local, solver, out=None):

@@ -119,14 +119,17 @@ typedef struct hdem_fill_stats {
     int32_t tile_h, tile_w;   /* tile shape in cells                         */
     int32_t visits_flat;      /* of tile_visits: tiles under one flat level, settled from
                                  their halo ring alone (no window load)         */
-    int32_t async_timed_out;  /* != 0: the asynchronous launch gave up (1 wall-clock
-                                 budget, 2 workgroups not co-resident); the round driver
-                                 finished the fill                              */
+    int32_t async_timed_out;  /* != 0: the asynchronous launch gave up (wall-clock
+                                 budget); the round driver finished the fill     */
     int64_t iterations;       /* 4-scan iterations, summed over tile visits  */
     int64_t visits_unchanged; /* visits that found nothing to lower          */
     int64_t visits_requeued;  /* visits that hit the iteration cap           */
     int64_t round_visits;     /* of tile_visits: made by the round driver    */
     int64_t pending;          /* tiles still queued when a time slice ended  */
+    int32_t partial_residency;/* 1: some workgroups of the asynchronous launch were not
+                                 resident within 200 us (the GPU is shared); the others
+                                 started without them and took their tiles       */
+    int32_t reserved;
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */
