@@ -762,3 +762,43 @@ def test_flat_path_with_the_coarse_start(monkeypatch):
     assert np.array_equal(wd.to_host(), c_oracle.sinkfill_pflood(z))
     assert st["visits_flat"] > 0
     wd.free()
+
+
+def test_two_fills_sharing_the_gpu_stay_exact():
+    """Two persistent fill launches at once (two contexts, two host threads): neither gets
+    all of its workgroups resident.  Round 1 fell back to the round driver in that case;
+    now the launch runs with the workgroups it gets -- their queued tiles are stolen -- and
+    says so in `partial_residency`.  The bits are the oracle's either way."""
+    import threading
+    zs = [oracle.synth_dem(3000, 3000), oracle.synth_dem(3000, 3000, variant="srtm")]
+    wants = [c_oracle.sinkfill_pflood(z) for z in zs]
+    seen = [[], []]
+    errors = []
+    start = threading.Barrier(2)
+
+    def run(k):
+        try:
+            ctx = backend.Context(0)
+            zd = backend.DeviceRaster.from_host(zs[k], ctx=ctx)
+            wd = backend.DeviceRaster.empty(zs[k].shape, np.float32, ctx)
+            for _ in range(4):
+                start.wait()
+                _, st = backend.sinkfill_dev(zd, out=wd)
+                assert st["converged"]
+                assert np.array_equal(wd.to_host(), wants[k])
+                seen[k].append((st["partial_residency"], st["async_timed_out"]))
+            zd.free()
+            wd.free()
+            ctx.close()
+        except BaseException as exc:                        # pylint: disable=broad-except
+            errors.append(exc)
+            start.abort()
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    print("partial residency / budget per call:", seen)
+    assert all(timed_out == 0 for calls in seen for _, timed_out in calls)
