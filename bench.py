@@ -84,6 +84,9 @@ def launch_ranks(n):
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n),
                    LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # as torch.distributed.run does: N ranks with a full OpenMP team each oversubscribe
+        # the host (measured: 246 against 8.8 ms per step in the two-rank rehearsal)
+        env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                       env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr))
     line, failed = b"", None
