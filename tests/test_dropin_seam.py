@@ -99,3 +99,42 @@ def test_custom_filters_namespace_covers_the_reference_module():
               f"missing = [n for n in {names + own!r} if not hasattr(m, n)]\n"
               "assert not missing, missing\nprint('ok')\n")
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+REF_TESTS = "/root/reference/cguerrero/tests"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_TESTS, "test_sliding_window.py")),
+                    reason="the reference tree is only present in the build container")
+def test_the_references_own_sliding_window_tests_behave_the_same_against_the_dropin():
+    """`cguerrero/tests/test_sliding_window.py` -- the reference's own 16 test methods with
+    their known-answer literals (`tests/constants.py`) -- run unmodified, in fresh
+    interpreters, once against the reference tree and once with `dropin/` first on `sys.path`
+    (its `from cguerrero.hydrodem.sliding_window import ...` then binds this package's
+    classes): the same tests pass and the same tests fail.  (With NumPy 2 two of the
+    reference's tests raise on its own code -- `array == array` of different shapes -- and do
+    the same here.  Runs where the reference tree is; the committed goldens of
+    tests/test_sliding_window.py carry the same windows to the GPU box.)"""
+    body = f"""
+        import unittest
+        sys.path.append({REF_TESTS!r})                 # `from constants import ...`
+        sys.dont_write_bytecode = True
+        import test_sliding_window as t
+        print('BOUND', t.SlidingWindow.__module__)
+        suite = unittest.defaultTestLoader.loadTestsFromModule(t)
+        result = unittest.TextTestRunner(verbosity=0, stream=open(os.devnull, 'w')).run(suite)
+        bad = sorted(str(test).split()[0] for test, _ in result.failures + result.errors)
+        print('RAN', result.testsRun, 'BAD', ','.join(bad))
+        """
+    mine = run("import os\n" + textwrap.dedent(body))
+    ref_head = ("import sys, os\nsys.path[:0] = ['/root/reference', "
+                "'/root/reference/cguerrero/hydrodem']\n")
+    theirs = subprocess.run([sys.executable, "-c", ref_head + textwrap.dedent(body)],
+                            capture_output=True, text=True, cwd="/")
+    assert mine.returncode == 0 and theirs.returncode == 0, mine.stderr + theirs.stderr
+    pick = lambda out, key: [ln for ln in out.stdout.splitlines() if ln.startswith(key)][0]
+    assert pick(mine, "BOUND") == "BOUND hydrodem_amd.sliding_window"
+    assert pick(theirs, "BOUND") == "BOUND cguerrero.hydrodem.sliding_window"
+    assert pick(mine, "RAN") == pick(theirs, "RAN")
+    ran, bad = pick(mine, "RAN").split(" BAD ")
+    assert ran == "RAN 16" and len([b for b in bad.split(",") if b]) <= 2
