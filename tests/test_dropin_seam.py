@@ -138,3 +138,33 @@ def test_the_references_own_sliding_window_tests_behave_the_same_against_the_dro
     assert pick(mine, "RAN") == pick(theirs, "RAN")
     ran, bad = pick(mine, "RAN").split(" BAD ")
     assert ran == "RAN 16" and len([b for b in bad.split(",") if b]) <= 2
+
+
+REF_SLIDING = "/root/reference/cguerrero/hydrodem/sliding_window.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SLIDING),
+                    reason="the reference tree is only present in the build container")
+def test_the_88_doctest_examples_of_the_references_sliding_window_hold_for_the_dropin():
+    """The known-answer literals of SURVEY 8c: every `>>>` example in the docstrings of the
+    reference's `sliding_window.py` (read as text, not imported), executed with `dropin/`
+    first on `sys.path` -- `from sliding_window import SlidingWindow` in the examples binds
+    this package's class -- prints exactly what the docstring says."""
+    code = f"""
+        import ast, doctest, io
+        tree = ast.parse(open({REF_SLIDING!r}).read())
+        docs = [(getattr(n, 'name', 'module'), ast.get_docstring(n, clean=False))
+                for n in ast.walk(tree) if isinstance(n, (ast.Module, ast.ClassDef, ast.FunctionDef))]
+        runner = doctest.DocTestRunner(verbose=False,
+                                       optionflags=doctest.NORMALIZE_WHITESPACE | doctest.ELLIPSIS)
+        sink = io.StringIO()
+        for name, doc in docs:
+            if doc and '>>>' in doc:
+                runner.run(doctest.DocTestParser().get_doctest(doc, {{}}, name, None, 0), out=sink.write)
+        import sliding_window
+        assert sliding_window.SlidingWindow.__module__ == 'hydrodem_amd.sliding_window'
+        print(runner.tries, runner.failures)
+        assert runner.tries == 88 and runner.failures == 0, sink.getvalue()[-3000:]
+        """
+    out = run(code)
+    assert out.returncode == 0, out.stdout + out.stderr
