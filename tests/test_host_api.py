@@ -179,6 +179,17 @@ def test_python_constants_match_the_header():
     assert int(enums["HDEM_K_FILL_ROUND"]) == backend.K_FILL_ROUND
     assert int(enums["HDEM_K_BLOCKMAX"]) == backend.K_BLOCKMAX
     assert int(enums["HDEM_K_GROVES"]) == backend.K_GROVES
+    assert int(enums["HDEM_K_COPY"]) == backend.K_COPY
+    assert int(enums["HDEM_K_FILL_COARSE"]) == backend.K_FILL_COARSE
+    assert int(enums["HDEM_K_FILL_FLAT"]) == backend.K_FILL_FLAT
+    assert int(enums["HDEM_K_ELEMENTWISE"]) == backend.K_ELEMENTWISE
+    ops = dict(re.findall(r"\b(HDEM_EW_[A-Z]+)\s*=\s*(\d+)", header))
+    assert [int(ops["HDEM_EW_" + n]) for n in ("MUL", "ADD", "RSUB", "GT", "LT", "NONZERO")] == \
+        [backend.EW_MUL, backend.EW_ADD, backend.EW_RSUB, backend.EW_GT, backend.EW_LT,
+         backend.EW_NONZERO]
+    types = dict(re.findall(r"\b(HDEM_T_[A-Z0-9]+)\s*=\s*(\d+)", header))
+    assert {np.dtype(np.float32): int(types["HDEM_T_F32"]), np.dtype(np.float64): int(types["HDEM_T_F64"]),
+            np.dtype(np.uint8): int(types["HDEM_T_U8"])} == backend._EW_TYPES
     assert int(enums["HDEM_ERR_WINDOW_EVEN"]) == backend.WINDOW_EVEN
     assert int(enums["HDEM_ERR_WINDOW_HIGH"]) == backend.WINDOW_HIGH
     assert int(enums["HDEM_ERR_NOT_CONVERGED"]) == backend.NOT_CONVERGED
