@@ -1266,9 +1266,10 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     ctx->start_coarse = nullptr;                // a caller's coarse raster is used once
     ctx->start_row_map = nullptr;
     fill_ws ws;
-    // (HDEM_FILL_WGS_PER_CU: experiments; the machine holds 8 of these one-wave workgroups per CU)
+    // (HDEM_FILL_WGS_PER_CU: experiments and tests; the machine holds 8 of these one-wave
+    // workgroups per CU -- more than 8 is a launch that cannot be resident at once)
     const int wgs_per_cu = getenv("HDEM_FILL_WGS_PER_CU") ? atoi(getenv("HDEM_FILL_WGS_PER_CU")) : 8;
-    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * std::max(1, std::min(wgs_per_cu, 8)),
+    if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * std::max(1, std::min(wgs_per_cu, 16)),
                            &resume, &ws))
         return rc;
     // not resumable: fine if the last call on this problem left nothing queued (then the ACT

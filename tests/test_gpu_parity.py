@@ -802,3 +802,66 @@ def test_two_fills_sharing_the_gpu_stay_exact():
     assert not errors, errors
     print("partial residency / budget per call:", seen)
     assert all(timed_out == 0 for calls in seen for _, timed_out in calls)
+
+
+def test_sinkfill_differential_over_random_rasters():
+    """120 seeded rasters of mixed character -- noise, integer steps, plateaus, bowls with
+    gapped rims, nodata blobs, shapes that are no multiple of anything -- each filled on the
+    GPU (with D8) and compared bit for bit with the C oracle; every fourth one with a
+    gradient.  Lakes wider than a tile take the flat path, nodata takes the wall path."""
+    rng = np.random.default_rng(20241005)
+    flat_calls = 0
+    for case in range(120):
+        h, w = int(rng.integers(3, 420)), int(rng.integers(3, 420))
+        if case % 10 == 0:
+            h, w = int(rng.integers(500, 900)), int(rng.integers(500, 900))
+        y, x = np.mgrid[0:h, 0:w]
+        z = 50 + rng.normal(0, rng.choice([0.05, 0.5, 3.0]), (h, w)) \
+            + rng.uniform(-0.05, 0.05) * x + rng.uniform(-0.05, 0.05) * y
+        kind = case % 6
+        if kind == 1:
+            z = np.round(z)                                   # flats and ties
+        elif kind == 2:
+            z[h // 4:h // 2, w // 5:w // 2] = 47.0            # a plateau below its surroundings
+        elif kind == 3 and min(h, w) > 40:
+            r = np.hypot(y - h / 2, x - w / 2) / (min(h, w) / 2)
+            z = np.where(r < 0.8, 30 + 5 * r + rng.normal(0, 0.2, (h, w)), z)
+            z[(r > 0.8) & (r < 0.9)] = 70.0                   # rim
+            z[:h // 2, w // 2 - 1:w // 2 + 1] = np.minimum(z[:h // 2, w // 2 - 1:w // 2 + 1], 41.0)
+        elif kind == 4:
+            for _ in range(int(rng.integers(1, 4))):
+                cy, cx = int(rng.integers(0, h)), int(rng.integers(0, w))
+                z[max(cy - 2, 0):cy + 3, max(cx - 4, 0):cx + 2] = np.nan
+        elif kind == 5:
+            z -= 5.0 * (rng.random((h, w)) < 0.01)            # pits
+        z = z.astype(np.float32)
+        eps = 1e-3 if case % 4 == 3 else 0.0
+        wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z), eps=eps)
+        want = c_oracle.sinkfill_pflood(z, eps=eps)
+        assert st["converged"], (case, h, w, kind, eps)
+        assert np.array_equal(wd.to_host(), want, equal_nan=True), (case, h, w, kind, eps)
+        assert np.array_equal(codes.to_host(), c_oracle.d8(want)), (case, h, w, kind, eps)
+        flat_calls += st["visits_flat"] > 0
+        wd.free()
+        codes.free()
+    assert flat_calls >= 3                                    # some of the bowls were wide enough
+
+
+def test_a_launch_that_cannot_be_resident_at_once_still_fills_exactly(monkeypatch):
+    """12 workgroups per CU where 8 fit: a third of the persistent launch is not resident when
+    it starts -- what a shared GPU looks like to it.  The resident workgroups wait 200 us,
+    start without the others, steal their tiles; the late ones find nothing queued."""
+    monkeypatch.setenv("HDEM_FILL_WGS_PER_CU", "12")
+    for variant, nodata in (("rough", False), ("srtm", True)):
+        z = oracle.synth_dem(4000, 3900, variant=variant)     # 4032 tiles > 12 x 256 workgroups
+        if nodata:
+            z[700:720, 900:1000] = np.nan
+        wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z))
+        want = c_oracle.sinkfill_pflood(z)
+        assert st["converged"] and st["async_timed_out"] == 0
+        assert st["partial_residency"] == 1
+        assert st["round_visits"] == 0                      # no fallback to the round driver
+        assert np.array_equal(wd.to_host(), want, equal_nan=True)
+        assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+        wd.free()
+        codes.free()
