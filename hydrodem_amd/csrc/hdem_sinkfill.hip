@@ -77,6 +77,9 @@ constexpr int STAT_FLAT = 7;
 #ifdef HDEM_VISIT_PROF
 constexpr int STAT_PROF = 8;
 #endif
+constexpr int HEAD_INTS = 32;          // head of the workspace: [0] budget / error flag,
+                                       // [1] residency census, [2] soft-budget flag,
+                                       // [3] partial residency, [4] certifying pass's flag
 constexpr int FLAT_NONE = 0x7f7f7f7f;  // "not flat" / "unknown" (what the 0x7f memset leaves)
 enum { ST_IDLE = 0, ST_QUEUED = 1, ST_RUNNING = 2, ST_DIRTY = 3, ST_ROUND0 = 16 };
 
@@ -1127,6 +1130,8 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
     }
 }
 
+size_t stat_ints_of(const fill_ws &ws) { return (size_t)ws.G * STAT_WORDS * 2; }
+
 int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, fill_ws *ws)
 {
     // tiles cover the interior (rows 1..H-2, cols 1..W-2); none if there is no interior
@@ -1138,7 +1143,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     ws->S = std::max(1, (ws->ntiles + ws->G - 1) / ws->G);
     const size_t n = (size_t)std::max(ws->ntiles, 1), gs = (size_t)ws->G * ws->S;
     const size_t stat_ints = (size_t)ws->G * STAT_WORDS * 2;
-    const size_t head = 32;                                        // error + pad (128 B)
+    const size_t head = HEAD_INTS;                                 // error + pad (128 B)
     const size_t ints = head + stat_ints + PEND_SHARDS * PEND_STRIDE + n + 2 * gs +
                         (size_t)max_rounds + 32 + 2 * n;
     const size_t bytes = ints * sizeof(int);
@@ -1153,7 +1158,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
         ctx->fill_ws_bytes = bytes;
         *resume = false;                                           // the worklist went with it
     }
-    const size_t host_ints = std::max(std::max(stat_ints, (size_t)max_rounds + 32),
+    const size_t host_ints = std::max(std::max(head + stat_ints, (size_t)max_rounds + 32),
                                        (size_t)PEND_SHARDS * PEND_STRIDE);
     if (ctx->host_counts_len < host_ints) {
         if (ctx->host_counts) HDEM_HIP_CHECK(hipHostFree(ctx->host_counts));
@@ -1161,28 +1166,27 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
         HDEM_HIP_CHECK(hipHostMalloc((void **)&ctx->host_counts, host_ints * sizeof(int32_t)));
         ctx->host_counts_len = host_ints;
     }
+    // Layout: [error | stats | any] [pend | state] [tile_key | prio] [flat | zmax] -- what is
+    // zeroed sits together and what is set to 0x7f.. sits together, so that a call costs two
+    // fill launches, not seven (each one is a kernel of its own, ~4 us on the stream).
     int *base = (int *)ctx->fill_ws;
+    const size_t any_ints = (size_t)max_rounds + 32, pend_ints = PEND_SHARDS * PEND_STRIDE;
     ws->error = base;
     ws->stats = (unsigned long long *)(base + head);               // 8-byte aligned
-    ws->pend = base + head + stat_ints;
-    ws->tile_key = ws->pend + PEND_SHARDS * PEND_STRIDE;
-    ws->state = ws->tile_key + n;
-    ws->prio = ws->state + gs;
-    ws->any = ws->prio + gs;
-    ws->flat = ws->any + (size_t)max_rounds + 32;
+    ws->any = base + head + stat_ints;
+    ws->pend = ws->any + any_ints;
+    ws->state = ws->pend + pend_ints;
+    ws->tile_key = ws->state + gs;
+    ws->prio = ws->tile_key + n;
+    ws->flat = ws->prio + gs;
     ws->zmax = ws->flat + n;
-    // (flat levels live inside one asynchronous launch: reset here, written out behind it)
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->flat, 0x7f, 2 * n * sizeof(int), ctx->stream));
-    // error, stats = 0; a resumed worklist keeps pend / state / prio of the last slice
-    HDEM_HIP_CHECK(hipMemsetAsync(base, 0, (head + stat_ints) * sizeof(int), ctx->stream));
-    if (!*resume) {
-        HDEM_HIP_CHECK(hipMemsetAsync(ws->pend, 0, PEND_SHARDS * PEND_STRIDE * sizeof(int),
-                                      ctx->stream));
-        HDEM_HIP_CHECK(hipMemsetAsync(ws->tile_key, 0x7f, n * sizeof(int), ctx->stream));
-        HDEM_HIP_CHECK(hipMemsetAsync(ws->state, 0, gs * sizeof(int), ctx->stream));
-        HDEM_HIP_CHECK(hipMemsetAsync(ws->prio, 0x7f, gs * sizeof(int), ctx->stream));
-    }
-    HDEM_HIP_CHECK(hipMemsetAsync(ws->any, 0, ((size_t)max_rounds + 32) * sizeof(int),
+    // error, stats, any = 0 and the flat levels reset (they live inside one asynchronous
+    // launch and are written out behind it); a resumed worklist keeps pend / state /
+    // tile_key / prio of the last slice
+    const size_t zeros = head + stat_ints + any_ints + (*resume ? 0 : pend_ints + gs);
+    HDEM_HIP_CHECK(hipMemsetAsync(base, 0, zeros * sizeof(int), ctx->stream));
+    int *sevens = *resume ? ws->flat : ws->tile_key;
+    HDEM_HIP_CHECK(hipMemsetAsync(sevens, 0x7f, (size_t)(ws->zmax + n - sevens) * sizeof(int),
                                   ctx->stream));
     return HDEM_OK;
 }
@@ -1302,6 +1306,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                            row_map);
     }
     int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
+    bool have_counts = false;          // head words + counters already on the host
     const bool did_async = use_async && ws.ntiles > 0;
     if (did_async) {
         // ---- asynchronous phase: does (nearly) all of the work -------------------
@@ -1380,14 +1385,18 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // (HDEM_FILL_CERTIFY_ROUNDS: always the rounds.)
     const bool sees_all = did_async || (warm && mode == 0);      // (as for d8 above)
     if (ws.ntiles > 0 && verify && sees_all && !getenv("HDEM_FILL_CERTIFY_ROUNDS")) {
-        int *flag = ws.any + max_rounds + 16;              // zeroed with any[]
+        int *flag = ws.error + 4;                          // (zeroed with the other head words)
         {
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_ROUND, (int64_t)H * W);
             if (int rc = hdem_certify_d8_launch(ctx, z, w, H, W, eps, d8, flag)) return rc;
         }
-        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        // one read-back for everything the host wants to know: the head words (budget flag,
+        // partial residency, the certifying pass's flag) and the per-workgroup counters sit
+        // next to each other.  Normally the flag is clear and this is the call's only wait.
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.error, (HEAD_INTS + stat_ints_of(ws)) * sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
-        if (ctx->host_counts[0] == 0) converged = 1;
+        if (ctx->host_counts[4] == 0) { converged = 1; have_counts = true; }
     }
     if (ws.ntiles > 0 && verify && !converged)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
@@ -1422,14 +1431,15 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     }
     // ---- statistics ----------------------------------------------------------------
     const size_t stat_words = (size_t)ws.G * STAT_WORDS;
-    unsigned long long *hs = (unsigned long long *)ctx->host_counts;
-    HDEM_HIP_CHECK(hipMemcpyAsync(hs, ws.stats, stat_words * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToHost, st));
-    HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
-    int partial_residency = 0;
-    HDEM_HIP_CHECK(hipMemcpyAsync(&partial_residency, ws.error + 3, sizeof(int),
-                                  hipMemcpyDeviceToHost, st));
-    HDEM_HIP_CHECK(hipStreamSynchronize(st));
+    if (!have_counts) {
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.error,
+                                      (HEAD_INTS + stat_ints_of(ws)) * sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
+        HDEM_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    const unsigned long long *hs = (const unsigned long long *)(ctx->host_counts + HEAD_INTS);
+    async_error = ctx->host_counts[0];
+    const int partial_residency = ctx->host_counts[3];
     unsigned long long tot[STAT_WORDS] = {};
     for (size_t i = 0; i < stat_words; ++i) tot[i % STAT_WORDS] += hs[i];
     // (visits of flat tiles touch ~500 cells, not a window: counted apart, stats->visits_flat)
