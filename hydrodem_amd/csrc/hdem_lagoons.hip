@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT) void correct_nan_kernel(const float *__restrict
 // the reference every NaN is its own Counter key and never wins; here the NaNs vote
 // together, which cannot unseat a value with the share (they are at most n - need), and
 // a NaN winner becomes "no majority" at the end.
-constexpr int MTX = 64, MTY = 32, MMAX = 15;
+constexpr int MTX = 64, MMAX = 15;
 constexpr unsigned NAN_KEY = 0x7fc00000u;
 
 __device__ __forceinline__ unsigned vote_key(float v)
@@ -88,34 +88,6 @@ __device__ __forceinline__ unsigned vote_key(float v)
     const unsigned b = __float_as_uint(v);
     return (b & 0x7fffffffu) > 0x7f800000u ? NAN_KEY : b == 0x80000000u ? 0u : b;
 }
-
-// One Boyer-Moore step with the K-th element of a segment, K known at compile time: with
-// q = (votes + K) / 2 a match is q + 1 and a mismatch leaves q alone, and votes can only
-// be 0 (the newcomer becomes the candidate) when K is even -- 3-4 operations per step on
-// average instead of 7.  The candidate is remembered as the column it was seen in
-// (4 bits), so a row summary is 16 bits of LDS -- candidate column and votes, for the
-// full and for the inner segment -- and 8 blocks fit a CU instead of 3 (the kernel waits
-// on its tile loads and on dependent operations, not on an execution unit).
-template <int WS, int K, int END>
-struct vote_run {
-    // cells: the inner columns 1 .. WS-2 first, then columns 0 and WS-1
-    static constexpr int COL = K < WS - 2 ? K + 1 : K == WS - 2 ? 0 : WS - 1;
-    static __device__ __forceinline__ void go(const unsigned *cells, unsigned &cand, unsigned &col,
-                                              unsigned &q)
-    {
-        if (K % 2 == 0) {
-            const bool fresh = q == K / 2;
-            cand = fresh ? cells[K] : cand;
-            col = fresh ? COL : col;
-        }
-        q += cells[K] == cand;
-        vote_run<WS, K + 1, END>::go(cells, cand, col, q);
-    }
-};
-template <int WS, int END>
-struct vote_run<WS, END, END> {
-    static __device__ __forceinline__ void go(const unsigned *, unsigned &, unsigned &, unsigned &) {}
-};
 
 // the summary (c2, v2) merged into (cand, votes)
 __device__ __forceinline__ void vote_merge(unsigned c2, unsigned v2, unsigned &cand, unsigned &votes)
@@ -125,92 +97,166 @@ __device__ __forceinline__ void vote_merge(unsigned c2, unsigned v2, unsigned &c
     cand = take ? c2 : cand;
 }
 
+// Kernel shape (64 staged rows x 64 + ws - 1 columns per 256-thread block):
+//   phase 1  a thread votes WRUN = 16 consecutive segments of one staged row out of the
+//            WRUN + ws - 1 keys it holds in registers (7 ds_read_b128 for 16 segments) and
+//            writes their 16-bit summaries -- candidate column and votes, of the full and
+//            of the inner segment -- as two 16-byte stores.  One Boyer-Moore step with
+//            the K-th cell, K known at compile time: with q = (votes + K) / 2 a match is
+//            q + 1 and a mismatch leaves q alone, and votes can only be 0 (the newcomer
+//            becomes the candidate) when K is even: 3-4 operations per step;
+//   phase 2  a thread walks down one output column with the summaries of its rows in
+//            registers; the sum of the rows' votes slides (one row in, one out).  A value
+//            present c times leaves at least 2 c_row - n_row votes in every row it leads
+//            and no row has negative votes, so the rows' votes add up to >= 2c - n: where
+//            they do not reach 2 need - n nothing has the share -- all of rough terrain;
+//   phase 3  the cells that pass are few and scattered (2.7 % of the cells of the bench
+//            raster, but at least one in 45 % of its wave-rows): they go to a queue in LDS
+//            and are merged / counted one per lane, instead of a whole wave running the
+//            merge for one lane.
+// Round 1's form (11 ds_read_b32 per segment, 11 summary reads per cell, merges where
+// they fell) took 1.67 ms at 16384^2; registers instead of LDS reads alone made it no
+// faster (the time was in the divergent merges), the queue did: 0.97 ms.
+constexpr int WTH = 64, WRUN = 16;
+
+template <int WS, int K, int END>
+struct vote_walk {
+    static constexpr int COL = K < WS - 2 ? K + 1 : K == WS - 2 ? 0 : WS - 1;
+    static __device__ __forceinline__ void go(const unsigned *row, unsigned &cand, unsigned &col,
+                                              unsigned &q)
+    {
+        if (K % 2 == 0) {
+            const bool fresh = q == K / 2;
+            cand = fresh ? row[COL] : cand;
+            col = fresh ? COL : col;
+        }
+        q += row[COL] == cand;
+        vote_walk<WS, K + 1, END>::go(row, cand, col, q);
+    }
+};
+template <int WS, int END>
+struct vote_walk<WS, END, END> {
+    static __device__ __forceinline__ void go(const unsigned *, unsigned &, unsigned &, unsigned &) {}
+};
+
 template <int WS>
-__global__ __launch_bounds__(NT) void majority_kernel(const float *__restrict__ in, int h, int w,
-                                                      int need, float *__restrict__ out)
+__global__ __launch_bounds__(NT) void majority_walk_kernel(const float *__restrict__ in, int h,
+                                                           int w, int need, float *__restrict__ out)
 {
     static_assert(WS <= 15, "columns and votes are packed in 4 bits");
-    constexpr int R = WS / 2, TW = MTX + 2 * R, TH = MTY + 2 * R, CELLS = WS * WS - 4;
-    __shared__ unsigned s[TH * TW];
-    // per row segment: full column | full votes << 4 | inner column << 8 | inner votes << 12
-    __shared__ unsigned short summary[TH * MTX];
-    const int x0 = blockIdx.x * MTX, y0 = blockIdx.y * MTY;
-    {   // every load of the thread in flight before the first one is used
-        constexpr int LOADS = (TW * TH + NT - 1) / NT;
+    constexpr int R = WS / 2, TW = MTX + 2 * R, TS = (TW + 3) / 4 * 4, ROWS = WTH - 2 * R;
+    constexpr int CELLS = WS * WS - 4, RPW = (ROWS + 3) / 4;
+    constexpr int NK = WRUN + WS - 1, NQ = (NK + 3) / 4;
+    static_assert(3 * WRUN + NQ * 4 <= TS, "the last run reads past its row");
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned s[WTH * TS];
+    __shared__ __attribute__((aligned(16))) unsigned short summary[WTH * MTX];
+    __shared__ unsigned short queue[ROWS * MTX];
+    __shared__ unsigned queued;
+    const int x0 = blockIdx.x * MTX, y0 = blockIdx.y * ROWS;
+    {
+        constexpr int LOADS = (TS * WTH + NT - 1) / NT;
         float v[LOADS];
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
-            const int k = threadIdx.x + j * NT, ly = k / TW, lx = k - ly * TW;
+            const int k = threadIdx.x + j * NT, ly = k / TS, lx = k - ly * TS;
             const int gy = y0 - R + ly, gx = x0 - R + lx;
-            v[j] = (k < TW * TH && gy >= 0 && gy < h && gx >= 0 && gx < w)
+            v[j] = (k < TS * WTH && gy >= 0 && gy < h && gx >= 0 && gx < w)
                        ? in[(size_t)gy * w + gx] : __builtin_nanf("");
         }
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
             const int k = threadIdx.x + j * NT;
-            if (k < TW * TH) s[k] = vote_key(v[j]);
+            if (k < TS * WTH) s[k] = vote_key(v[j]);
         }
     }
     __syncthreads();
-    const int lx = threadIdx.x % MTX;
-    for (int ly = threadIdx.x / MTX; ly < TH; ly += NT / MTX) {
-        const unsigned *row = s + ly * TW + lx;
-        unsigned cells[WS];
+    {
+        const int ly = threadIdx.x >> 2, run = threadIdx.x & 3;
+        unsigned keys[NQ * 4];
+        const u4 *src = reinterpret_cast<const u4 *>(s + ly * TS + run * WRUN);
 #pragma unroll
-        for (int k = 0; k < WS - 2; ++k) cells[k] = row[1 + k];
-        cells[WS - 2] = row[0];
-        cells[WS - 1] = row[WS - 1];
-        unsigned cand = 0, col = 0, q = 0;
-        vote_run<WS, 0, WS - 2>::go(cells, cand, col, q);
-        const unsigned inner = col | ((2 * q - (WS - 2)) << 4);
-        vote_run<WS, WS - 2, WS>::go(cells, cand, col, q);
-        summary[ly * MTX + lx] = (unsigned short)(col | ((2 * q - WS) << 4) | (inner << 8));
+        for (int k = 0; k < NQ; ++k) {
+            const u4 q4 = src[k];
+            keys[4 * k] = q4[0]; keys[4 * k + 1] = q4[1]; keys[4 * k + 2] = q4[2]; keys[4 * k + 3] = q4[3];
+        }
+        unsigned packed[WRUN / 2];
+#pragma unroll
+        for (int i = 0; i < WRUN; ++i) {
+            unsigned cand = 0, col = 0, q = 0;
+            vote_walk<WS, 0, WS - 2>::go(keys + i, cand, col, q);
+            const unsigned inner = col | ((2 * q - (WS - 2)) << 4);
+            vote_walk<WS, WS - 2, WS>::go(keys + i, cand, col, q);
+            const unsigned sum16 = col | ((2 * q - WS) << 4) | (inner << 8);
+            if (i % 2 == 0) packed[i / 2] = sum16; else packed[i / 2] |= sum16 << 16;
+        }
+        u4 *dst = reinterpret_cast<u4 *>(summary + ly * MTX + run * WRUN);
+        dst[0] = (u4){packed[0], packed[1], packed[2], packed[3]};
+        dst[1] = (u4){packed[4], packed[5], packed[6], packed[7]};
     }
     __syncthreads();
-    for (int ly = threadIdx.x / MTX; ly < MTY; ly += NT / MTX) {
-        const int x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h) continue;
+    const int lx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPW;
+    const int x = x0 + lx;
+    unsigned sm[RPW + WS - 1];
+#pragma unroll
+    for (int k = 0; k < RPW + WS - 1; ++k) sm[k] = summary[min(r0 + k, WTH - 1) * MTX + lx];
+    int mid = 0;                                    // full-segment votes of rows 1 .. ws-2
+#pragma unroll
+    for (int dy = 1; dy < WS - 1; ++dy) mid += (sm[dy] >> 4) & 15u;
+    unsigned pass = 0;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int y = y0 + r0 + i;
+        const int vote_sum = mid + (int)(sm[i] >> 12) + (int)(sm[i + WS - 1] >> 12);
+        const bool inside = r0 + i < ROWS && y >= R && y < h - R && x >= R && x < w - R;
+        pass |= (unsigned)(inside && vote_sum >= 2 * need - CELLS) << i;
+        mid += (int)((sm[i + WS - 1] >> 4) & 15u) - (int)((sm[i + 1] >> 4) & 15u);
+    }
+    if (threadIdx.x == 0) queued = 0;
+    __syncthreads();
+    if (pass) {
+        unsigned at = atomicAdd(&queued, (unsigned)__builtin_popcount(pass));
+        for (unsigned m = pass; m; m &= m - 1)
+            queue[at++] = (unsigned short)((r0 + __builtin_ctz(m)) << 6 | lx);
+    }
+    if (x < w) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int y = y0 + r0 + i;
+            if (r0 + i < ROWS && y < h && !(pass >> i & 1u)) out[(size_t)y * w + x] = 0.0f;
+        }
+    }
+    __syncthreads();
+    const unsigned total = queued;
+    for (unsigned q = threadIdx.x; q < total; q += NT) {
+        const int ly = queue[q] >> 6, cx = queue[q] & 63;
+        const unsigned *col0 = s + ly * TS + cx;
+        unsigned rows[WS];
+        rows[0] = summary[ly * MTX + cx] >> 8;
+#pragma unroll
+        for (int dy = 1; dy < WS - 1; ++dy) rows[dy] = summary[(ly + dy) * MTX + cx] & 0xffu;
+        rows[WS - 1] = summary[(ly + WS - 1) * MTX + cx] >> 8;
+        unsigned cand = col0[rows[0] & 15u], votes = rows[0] >> 4;
+#pragma unroll
+        for (int dy = 1; dy < WS; ++dy)
+            vote_merge(col0[dy * TS + (rows[dy] & 15u)], rows[dy] >> 4, cand, votes);
         unsigned result = 0;
-        if (y >= R && y < h - R && x >= R && x < w - R) {
-            const unsigned *col0 = s + ly * TW + lx;
-            // the row summaries of the window (top and bottom row: the inner segment)
-            unsigned rows[WS];
-            rows[0] = summary[ly * MTX + lx] >> 8;
+        if (cand == NAN_KEY) {
+            // no value has the share
+        } else if ((int)votes >= need) {
+            result = cand;                          // the summary holds `votes` copies of it
+        } else if ((int)votes >= 2 * need - CELLS) {
+            int count = 0;
 #pragma unroll
-            for (int dy = 1; dy < WS - 1; ++dy) rows[dy] = summary[(ly + dy) * MTX + lx] & 0xffu;
-            rows[WS - 1] = summary[(ly + WS - 1) * MTX + lx] >> 8;
-            // A value present c times leaves at least 2 c_row - n_row votes in every row it
-            // leads and no row has negative votes, so the rows' votes add up to >= 2c - n:
-            // where they do not reach 2 need - n nothing has the share, and the merges (with
-            // their dependent reads, most of this kernel) are skipped -- all of rough terrain.
-            unsigned vote_sum = 0;
+            for (int dy = 0; dy < WS; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < WS; ++dy) vote_sum += rows[dy] >> 4;
-            unsigned cand = NAN_KEY, votes = 0;
-            if ((int)vote_sum >= 2 * need - CELLS) {
-                cand = col0[rows[0] & 15u];
-                votes = rows[0] >> 4;
-#pragma unroll
-                for (int dy = 1; dy < WS; ++dy)
-                    vote_merge(col0[dy * TW + (rows[dy] & 15u)], rows[dy] >> 4, cand, votes);
-            }
-            if (cand == NAN_KEY) {
-                // no value has the share
-            } else if ((int)votes >= need) {
-                result = cand;                      // the summary holds `votes` copies of it
-            } else if ((int)votes >= 2 * need - CELLS) {
-                int count = 0;
-#pragma unroll
-                for (int dy = 0; dy < WS; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < WS; ++dx) {
-                        if ((dy == 0 || dy == WS - 1) && (dx == 0 || dx == WS - 1)) continue;
-                        count += col0[dy * TW + dx] == cand;
-                    }
-                if (count >= need) result = cand;
-            }
+                for (int dx = 0; dx < WS; ++dx) {
+                    if ((dy == 0 || dy == WS - 1) && (dx == 0 || dx == WS - 1)) continue;
+                    count += col0[dy * TS + dx] == cand;
+                }
+            if (count >= need) result = cand;
         }
-        out[(size_t)y * w + x] = __uint_as_float(result);
+        out[(size_t)(y0 + ly) * w + x0 + cx] = __uint_as_float(result);
     }
 }
 
@@ -569,12 +615,13 @@ extern "C" int hdem_majority_f32_dev(hdem_ctx *ctx, const float *img, int H, int
     while ((double)need <= thr) ++need;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_MAJORITY, (int64_t)H * W);
-        const dim3 grid((W + MTX - 1) / MTX, (H + MTY - 1) / MTY);
         switch (window) {
 #define HDEM_MAJORITY(WS_)                                                                     \
     case WS_:                                                                                  \
-        hipLaunchKernelGGL(majority_kernel<WS_>, grid, dim3(NT), 0, ctx->stream, img, H, W,   \
-                           need, out);                                                         \
+        hipLaunchKernelGGL(majority_walk_kernel<WS_>,                                          \
+                           dim3((W + MTX - 1) / MTX,                                           \
+                                (H + WTH - 2 * (WS_ / 2) - 1) / (WTH - 2 * (WS_ / 2))),        \
+                           dim3(NT), 0, ctx->stream, img, H, W, need, out);                    \
         break;
             HDEM_MAJORITY(3) HDEM_MAJORITY(5) HDEM_MAJORITY(7) HDEM_MAJORITY(9)
             HDEM_MAJORITY(11) HDEM_MAJORITY(13) HDEM_MAJORITY(15)

@@ -109,3 +109,40 @@ def test_bench_starts_its_own_ranks(built):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size",
                           "-5"], env=env, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+def _rccl_worker(rank, world, port, H, W, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from hydrodem_amd import partition as P
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        z = oracle.synth_dem(H, W)
+        zt = torch.from_numpy(z).cuda()
+        solver = P.HipLocalSolver(0)
+        comm = P.DistComm()
+        assert not comm.gloo
+        d = torch.empty(zt.shape, dtype=torch.uint8, device=zt.device)
+        w, info = P.sinkfill_distributed(zt, rank, world, solver, d8_out=d, comm=comm)
+        # the two collectives of the schedule on device tensors, through RCCL itself
+        word = torch.tensor([rank + 3], dtype=torch.int32, device=zt.device)
+        assert int(comm.all_reduce_max(word).item()) == world + 2
+        parts = comm.all_gather(torch.arange(4, device=zt.device) + rank)
+        assert len(parts) == world and parts[0].tolist() == [0, 1, 2, 3]
+        torch.cuda.synchronize()
+        np.savez(os.path.join(outdir, "r0.npz"), w=w.cpu().numpy(), d=d.cpu().numpy(),
+                 solves=info["solves"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_world_of_one(tmp_path, built):
+    """The `nccl` (= RCCL) backend on the one GPU of the box: a world of one rank has no
+    neighbour to swap with, but the process group, the device MAX-reduce of the vote and
+    the all-gather of the coarse start run through RCCL, on the library's stream order."""
+    H, W = 900, 1100
+    mp.spawn(_rccl_worker, args=(1, _free_port(), H, W, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "r0.npz")
+    want = c_oracle.sinkfill_pflood(oracle.synth_dem(H, W))
+    assert np.array_equal(got["w"], want) and np.array_equal(got["d"], c_oracle.d8(want))
