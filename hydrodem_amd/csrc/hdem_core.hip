@@ -1,6 +1,8 @@
 // Context, memory, error and profiling plumbing of libhydrodem_hip.so.
 #include "hdem_internal.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -71,7 +73,12 @@ extern "C" int hdem_shutdown(hdem_ctx *ctx)
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    for (auto &b : ctx->pool_free) {
+        (void)hipFree(b.p);
+        (void)hipEventDestroy(b.ready);
+    }
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->pool_events) (void)hipEventDestroy(ev);
     hdem_fourier_release(ctx);
     if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
     if (ctx->coarse_buf) (void)hipFree(ctx->coarse_buf);
@@ -116,12 +123,61 @@ extern "C" int hdem_synchronize(hdem_ctx *ctx)
     return HDEM_OK;
 }
 
+namespace {
+
+void pool_drop(hdem_ctx *ctx, size_t keep_bytes)
+{
+    // oldest first; hipFree waits for the device, which also covers `ready`
+    size_t i = 0;
+    for (; i < ctx->pool_free.size() && ctx->pool_bytes > keep_bytes; ++i) {
+        hdem_cached_block &b = ctx->pool_free[i];
+        (void)hipFree(b.p);
+        ctx->pool_events.push_back(b.ready);
+        ctx->pool_bytes -= b.bytes;
+    }
+    ctx->pool_free.erase(ctx->pool_free.begin(), ctx->pool_free.begin() + (long)i);
+}
+
+}  // namespace
+
 extern "C" int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr)
 {
     HDEM_REQUIRE(ctx && dptr, HDEM_ERR_BAD_ARG, "null argument");
     *dptr = nullptr;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
-    HDEM_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1));
+    if (!bytes) bytes = 1;
+    std::lock_guard<std::mutex> guard(ctx->pool_lock);
+    // smallest cached block that holds the request without wasting more than an eighth
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool_free.size(); ++i) {
+        const size_t have = ctx->pool_free[i].bytes;
+        if (have >= bytes && have - bytes <= bytes / 8 &&
+            (best < 0 || have < ctx->pool_free[best].bytes))
+            best = i;
+    }
+    if (best >= 0) {
+        const hdem_cached_block b = ctx->pool_free[best];
+        ctx->pool_free.erase(ctx->pool_free.begin() + best);
+        ctx->pool_bytes -= b.bytes;
+        // whatever still runs on the block was enqueued before `ready`
+        HDEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, b.ready, 0));
+        ctx->pool_events.push_back(b.ready);
+        ctx->pool_live[b.p] = b.bytes;
+        *dptr = b.p;
+        return HDEM_OK;
+    }
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {
+        (void)hipGetLastError();
+        pool_drop(ctx, 0);
+        e = hipMalloc(dptr, bytes);
+    }
+    if (e != hipSuccess) {
+        *dptr = nullptr;
+        hdem_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? HDEM_ERR_OOM : HDEM_ERR_HIP;
+    }
+    ctx->pool_live[*dptr] = bytes;
     return HDEM_OK;
 }
 
@@ -130,6 +186,35 @@ extern "C" int hdem_free(hdem_ctx *ctx, void *dptr)
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
     if (!dptr) return HDEM_OK;
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> guard(ctx->pool_lock);
+    const auto it = ctx->pool_live.find(dptr);
+    const size_t bytes = it == ctx->pool_live.end() ? 0 : it->second;
+    if (it != ctx->pool_live.end()) ctx->pool_live.erase(it);
+    if (!ctx->pool_cap) {
+        // a quarter of the device, at most 64 GiB (HDEM_POOL_MIB: another figure, 0 = keep nothing)
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        ctx->pool_cap = std::min<size_t>(total_b / 4, (size_t)64 << 30);
+        if (const char *e = getenv("HDEM_POOL_MIB")) ctx->pool_cap = (size_t)atoll(e) << 20;
+        if (!ctx->pool_cap) ctx->pool_cap = 1;          // "looked up"; nothing fits
+    }
+    if (bytes && bytes <= ctx->pool_cap) {
+        hipEvent_t ev = nullptr;
+        if (!ctx->pool_events.empty()) {
+            ev = ctx->pool_events.back();
+            ctx->pool_events.pop_back();
+        } else if (hipEventCreateWithFlags(&ev, hipEventDefault) != hipSuccess) {
+            ev = nullptr;
+        }
+        if (ev && hipEventRecord(ev, ctx->stream) == hipSuccess) {
+            if (ctx->pool_bytes + bytes > ctx->pool_cap) pool_drop(ctx, ctx->pool_cap - bytes);
+            ctx->pool_free.push_back({dptr, bytes, ev});
+            ctx->pool_bytes += bytes;
+            return HDEM_OK;
+        }
+        if (ev) ctx->pool_events.push_back(ev);
+    }
+    // not one of ours, larger than the cache, or no event to be had: the plain way
     HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     HDEM_HIP_CHECK(hipFree(dptr));
     return HDEM_OK;

@@ -925,10 +925,10 @@ extern "C" int hdem_fourier_destripe_f32(hdem_ctx *ctx, const float *dem, int H,
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t n = (size_t)H * W;
     hdem_dbuf d_in, d_out, d_mask;
-    if (int rc = d_in.alloc(n * sizeof(float))) return rc;
-    if (int rc = d_out.alloc(n * sizeof(float))) return rc;
+    if (int rc = d_in.alloc(ctx, n * sizeof(float))) return rc;
+    if (int rc = d_out.alloc(ctx, n * sizeof(float))) return rc;
     if (mask)
-        if (int rc = d_mask.alloc(n)) return rc;
+        if (int rc = d_mask.alloc(ctx, n)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, d_in.p, dem, n * sizeof(float))) return rc;
     if (int rc = hdem_fourier_destripe_f32_dev(ctx, (const float *)d_in.p, H, W, (float *)d_out.p,
                                                mask ? (uint8_t *)d_mask.p : nullptr))

@@ -474,8 +474,8 @@ extern "C" int hdem_quadratic_f32(hdem_ctx *ctx, const float *dem, int H, int W,
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t bytes = (size_t)H * W * sizeof(float);
     hdem_dbuf din, dout;
-    if (int rc = din.alloc(bytes)) return rc;
-    if (int rc = dout.alloc(bytes)) return rc;
+    if (int rc = din.alloc(ctx, bytes)) return rc;
+    if (int rc = dout.alloc(ctx, bytes)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, din.p, dem, bytes)) return rc;
     if (int rc = hdem_quadratic_f32_dev(ctx, (const float *)din.p, H, W, ws, (float *)dout.p))
         return rc;
@@ -493,10 +493,10 @@ extern "C" int hdem_groves_f32(hdem_ctx *ctx, const float *img, const uint8_t *g
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t n = (size_t)H * W, bytes = n * sizeof(float);
     hdem_dbuf din, dout, dscr, dg;
-    if (int rc = din.alloc(bytes)) return rc;
-    if (int rc = dout.alloc(bytes)) return rc;
-    if (iters > 1) if (int rc = dscr.alloc(bytes)) return rc;
-    if (int rc = dg.alloc(n)) return rc;
+    if (int rc = din.alloc(ctx, bytes)) return rc;
+    if (int rc = dout.alloc(ctx, bytes)) return rc;
+    if (iters > 1) if (int rc = dscr.alloc(ctx, bytes)) return rc;
+    if (int rc = dg.alloc(ctx, n)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, din.p, img, bytes)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dg.p, groves, n)) return rc;
     if (int rc = hdem_groves_f32_dev(ctx, (const float *)din.p, (const uint8_t *)dg.p, H, W,

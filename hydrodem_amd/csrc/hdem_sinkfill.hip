@@ -1550,8 +1550,8 @@ extern "C" int hdem_sinkfill_f32(hdem_ctx *ctx, const float *z, int H, int W, fl
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)H * W * sizeof(float);
     hdem_dbuf dz, dw;
-    if (int rc = dz.alloc(bytes)) return rc;
-    if (int rc = dw.alloc(bytes)) return rc;
+    if (int rc = dz.alloc(ctx, bytes)) return rc;
+    if (int rc = dw.alloc(ctx, bytes)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dz.p, z, bytes)) return rc;
     int rc = hdem_sinkfill_f32_dev(ctx, (const float *)dz.p, H, W, eps, max_rounds,
                                    HDEM_FILL_INIT, (float *)dw.p, stats);

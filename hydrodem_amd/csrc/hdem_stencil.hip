@@ -402,8 +402,8 @@ extern "C" int hdem_d8_f32(hdem_ctx *ctx, const float *z, int H, int W, uint8_t 
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t n = (size_t)H * W;
     hdem_dbuf dz, dout;
-    if (int rc = dz.alloc(n * sizeof(float))) return rc;
-    if (int rc = dout.alloc(n)) return rc;
+    if (int rc = dz.alloc(ctx, n * sizeof(float))) return rc;
+    if (int rc = dout.alloc(ctx, n)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dz.p, z, n * sizeof(float))) return rc;
     if (int rc = hdem_d8_f32_dev(ctx, (const float *)dz.p, H, W, (uint8_t *)dout.p)) return rc;
     return hdem_memcpy_d2h(ctx, out, dout.p, n);
@@ -435,8 +435,8 @@ static int boxmean_host(hdem_ctx *ctx, const T *x, int H, int W, int do_round, T
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t bytes = (size_t)H * W * sizeof(T);
     hdem_dbuf dx, dout;
-    if (int rc = dx.alloc(bytes)) return rc;
-    if (int rc = dout.alloc(bytes)) return rc;
+    if (int rc = dx.alloc(ctx, bytes)) return rc;
+    if (int rc = dout.alloc(ctx, bytes)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dx.p, x, bytes)) return rc;
     if (int rc = boxmean_dev<T>(ctx, (const T *)dx.p, H, W, do_round, (T *)dout.p)) return rc;
     return hdem_memcpy_d2h(ctx, out, dout.p, bytes);
@@ -464,9 +464,9 @@ extern "C" int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t n = (size_t)H * W;
     hdem_dbuf dx, dout, dw;
-    if (int rc = dx.alloc(n * sizeof(float))) return rc;
-    if (int rc = dout.alloc(n * sizeof(float))) return rc;
-    if (int rc = dw.alloc(sizeof(double) * kh * kw)) return rc;
+    if (int rc = dx.alloc(ctx, n * sizeof(float))) return rc;
+    if (int rc = dout.alloc(ctx, n * sizeof(float))) return rc;
+    if (int rc = dw.alloc(ctx, sizeof(double) * kh * kw)) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dx.p, x, n * sizeof(float))) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dw.p, weights, sizeof(double) * kh * kw)) return rc;
     {
@@ -486,7 +486,7 @@ static int around_host(hdem_ctx *ctx, const T *x, int64_t n, T *out)
     HDEM_REQUIRE(n > 0, HDEM_ERR_BAD_ARG, "n must be positive");
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     hdem_dbuf dx;
-    if (int rc = dx.alloc((size_t)n * sizeof(T))) return rc;
+    if (int rc = dx.alloc(ctx, (size_t)n * sizeof(T))) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dx.p, x, (size_t)n * sizeof(T))) return rc;
     hipLaunchKernelGGL(around_kernel<T>, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                        ctx->stream, (const T *)dx.p, n, (T *)dx.p);

@@ -54,7 +54,13 @@ int hdem_shutdown(hdem_ctx *ctx);
 int hdem_set_stream(hdem_ctx *ctx, void *hip_stream);
 int hdem_synchronize(hdem_ctx *ctx);
 
-/* ---- device memory (so that a host needs nothing but this library) ------ */
+/* ---- device memory (so that a host needs nothing but this library) ------
+ * hdem_free keeps the block (up to a quarter of the device's memory, at most 64 GiB;
+ * HDEM_POOL_MIB in the environment: another figure, 0 = none) and hdem_malloc hands it out
+ * again for a request of that size or up to an eighth less; the new owner's stream waits
+ * for whatever the context's stream held at the time of the free -- no host wait, no
+ * hipMalloc / hipFree in a chain of operators that allocates at every call.  A block is
+ * handed back on the context it came from; hdem_shutdown returns everything. */
 int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr);
 int hdem_free(hdem_ctx *ctx, void *dptr);
 int hdem_memcpy_h2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
