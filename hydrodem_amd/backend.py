@@ -90,11 +90,11 @@ SIGNATURES = {
     "hdem_elementwise_dev": [_vp, _i, _vp, _i, _vp, _i, _c.c_double, _c.c_int64, _vp, _i],
     "hdem_fourier_destripe_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "hdem_fourier_destripe_f32_dev": [_vp, _vp, _i, _i, _vp, _vp],
-    "hdem_blanks_fourier_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_blanks_fourier_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_isolated_points_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_expand_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_fft2_c2c_f32_dev": [_vp, _vp, _i, _i, _i],
-    "hdem_correct_nan_f32_dev": [_vp, _vp, _i, _i, _vp],
+    "hdem_correct_nan_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_majority_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_binary_erosion_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp],
     "hdem_binary_closing_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
@@ -443,14 +443,15 @@ def fourier_destripe_dev(dem, out=None, mask=None):
     return out
 
 
-def blanks_fourier_dev(q, found=None):
+def blanks_fourier_dev(q, found=None, window_size=55):
     """One BlanksFourier pass: returns the byte mask of cells above 4x their hollow
     mean; ``q`` is rewritten with those cells zeroed."""
     _need(q, np.float32)
     c = q.ctx
     found = found or DeviceRaster.empty(q.shape, np.uint8, c)
     c.check(c.lib.hdem_blanks_fourier_f32_dev(c.handle, q.ptr, q.shape[0], q.shape[1],
-                                              found.ptr), window=55, shape=q.shape)
+                                              int(window_size), found.ptr),
+            window=window_size, shape=q.shape)
     return found
 
 
@@ -483,12 +484,13 @@ def fft2_dev(data, inverse=False):
     return data
 
 
-def correct_nan_dev(dem, out=None):
+def correct_nan_dev(dem, out=None, window_size=3):
     _need(dem, np.float32)
     c = dem.ctx
     out = out or DeviceRaster.empty(dem.shape, np.float32, c)
     c.check(c.lib.hdem_correct_nan_f32_dev(c.handle, dem.ptr, dem.shape[0], dem.shape[1],
-                                           out.ptr), window=3, shape=dem.shape)
+                                           int(window_size), out.ptr),
+            window=window_size, shape=dem.shape)
     return out
 
 
@@ -733,10 +735,10 @@ def fourier_destripe(dem, return_mask=False):
     return (out, mask) if return_mask else out
 
 
-def blanks_fourier(q):
+def blanks_fourier(q, window_size=55):
     """(found float64 0/1, q * (1 - found)) like BlanksFourier.apply."""
     qd = DeviceRaster.from_host(_host2d(q, np.float32))
-    found = blanks_fourier_dev(qd)
+    found = blanks_fourier_dev(qd, window_size=window_size)
     return found.to_host().astype(np.float64), qd.to_host()
 
 

@@ -358,15 +358,18 @@ __device__ __forceinline__ double wave_scan_f64(double p)
     return p;
 }
 
-template <int R, int r>
+// RT: half the window, or 0 = taken from `reach` at run time (BlanksFourier windows other
+// than the 55 of the reference's pipeline)
+template <int RT, int r>
 __global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restrict__ q, int h, int w,
                                                            float factor, int seg,
                                                            float *__restrict__ q_out,
                                                            uint8_t *found, uint8_t *total,
                                                            uint8_t *occ_mark,
                                                            const uint8_t *__restrict__ occ_skip,
-                                                           int occ_w)
+                                                           int occ_w, int reach)
 {
+    const int R = RT ? RT : reach;
     // [buffer][row of the pair]: two rows share a block barrier, two buffers alternate
     __shared__ double pre[2][2][HT + 1];   // per-wave inclusive prefix of the big column sums
     __shared__ double sml[2][2][HT];       // small column sums
@@ -704,18 +707,24 @@ int check_window(int window, int h, int w)
 // needed), found / total as in detect_kernel.
 // occ_mark / occ_skip: ((h + 31) / 32) x ((w + 31) / 32) bytes, see the kernel; either may be NULL.
 int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8_t *found,
-                uint8_t *total, uint8_t *occ_mark = nullptr, const uint8_t *occ_skip = nullptr)
+                uint8_t *total, uint8_t *occ_mark = nullptr, const uint8_t *occ_skip = nullptr,
+                int window = 55)
 {
     // rows one block walks: long runs amortise the 2R-row start-up of the sliding sums,
     // short ones fill the chip on small quadrants (aim for >= 2048 blocks of 4 waves)
-    const int bx = (w + (HT - 54) - 1) / (HT - 54);
+    const int R = window / 2, per_block = HT - 2 * R;
+    const int bx = (w + per_block - 1) / per_block;
     int seg = 256;
     while (seg > 32 && (int64_t)bx * ((h + seg - 1) / seg) < 2048) seg /= 2;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_DETECT, (int64_t)h * w);
-        hipLaunchKernelGGL((hollow_detect_kernel<27, 2>), dim3(bx, (h + seg - 1) / seg), dim3(HT),
-                           0, ctx->stream, q, h, w, 4.0f, seg, q_out, found, total, occ_mark, occ_skip,
-                           (w + 31) / 32);
+        const dim3 grid(bx, (h + seg - 1) / seg);
+        if (window == 55)
+            hipLaunchKernelGGL((hollow_detect_kernel<27, 2>), grid, dim3(HT), 0, ctx->stream, q, h,
+                               w, 4.0f, seg, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, 27);
+        else
+            hipLaunchKernelGGL((hollow_detect_kernel<0, 2>), grid, dim3(HT), 0, ctx->stream, q, h, w,
+                               4.0f, seg, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, R);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
@@ -726,16 +735,21 @@ int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-extern "C" int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, uint8_t *found)
+extern "C" int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, int window,
+                                           uint8_t *found)
 {
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
     if (int rc = hdem_check_raster(q, found, h, w)) return rc;
-    if (int rc = check_window(55, h, w)) return rc;
+    if (int rc = check_window(window, h, w)) return rc;
+    // (the inner window left out is 5 x 5; a block of 256 columns keeps `window - 1` of them
+    // as context)
+    HDEM_REQUIRE(window >= 7 && window <= 201, HDEM_ERR_BAD_ARG,
+                 "BlanksFourier window must be 7..201, got %d", window);
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)h * w * sizeof(float);
     float *tmp = (float *)hdem_arena(ctx, bytes);          // the pass is out of place
     if (!tmp) return HDEM_ERR_OOM;
-    if (int rc = blanks_pass(ctx, q, h, w, tmp, found, nullptr)) return rc;
+    if (int rc = blanks_pass(ctx, q, h, w, tmp, found, nullptr, nullptr, nullptr, window)) return rc;
     HDEM_HIP_CHECK(hipMemcpyAsync(q, tmp, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return HDEM_OK;
 }

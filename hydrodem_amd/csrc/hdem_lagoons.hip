@@ -66,6 +66,42 @@ __global__ __launch_bounds__(NT) void correct_nan_kernel(const float *__restrict
     }
 }
 
+// Any odd window (the reference's own pipeline only uses 3): the neighbours >= 0 of the
+// ws x ws window without its centre, in row-major order, summed the way NumPy sums a
+// contiguous float32 vector of n < 128 values -- sequentially from 0 below 8 values; else
+// eight running sums over the blocks of 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+// then the n mod 8 values left over one by one -- and divided in double.  One cell per lane;
+// voids are rare.
+__global__ __launch_bounds__(NT) void correct_nan_ws_kernel(const float *__restrict__ in, int h,
+                                                            int w, int R, float *__restrict__ out)
+{
+    const int x = blockIdx.x * NT + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float v = in[(size_t)y * w + x];
+    float res = v;
+    if (v < 0.0f && y >= R && y < h - R && x >= R && x < w - R) {
+        float r[8], held[8];
+        int n = 0, nh = 0;
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dx = -R; dx <= R; ++dx) {
+                if (dy == 0 && dx == 0) continue;
+                const float t = in[(size_t)(y + dy) * w + x + dx];
+                if (!(t >= 0.0f)) continue;
+                held[nh++] = t;
+                ++n;
+                if (nh == 8) {                               // a whole block of 8
+                    for (int k = 0; k < 8; ++k) r[k] = n == 8 ? held[k] : r[k] + held[k];
+                    nh = 0;
+                }
+            }
+        float s = 0.0f;
+        if (n >= 8) s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int k = 0; k < nh; ++k) s += held[k];
+        res = n ? (float)((double)s / (double)n) : __builtin_nanf("");
+    }
+    out[(size_t)y * w + x] = res;
+}
+
 // MajorityFilter.apply (:44-73): the value held by more than 70 % of (ws^2 - 1) cells of
 // the ws x ws window minus its corners, else 0; only centres whose window fits.  A value
 // with that share is a strict majority, so a Boyer-Moore vote finds it and a count pass
@@ -583,17 +619,26 @@ int erode_n(hdem_ctx *ctx, const uint8_t *in, int h, int w, const morph_struct &
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-extern "C" int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W, float *out)
+extern "C" int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W, int window,
+                                        float *out)
 {
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
     if (int rc = hdem_check_raster(dem, out, H, W)) return rc;
     HDEM_REQUIRE(dem != out, HDEM_ERR_BAD_ARG, "the NaN correction cannot run in place");
-    if (int rc = window_ok(3, H, W)) return rc;
+    HDEM_REQUIRE(window >= 3, HDEM_ERR_BAD_ARG, "window must be >= 3, got %d", window);
+    if (int rc = window_ok(window, H, W)) return rc;
+    // (NumPy's sum changes shape again at 128 values: windows up to 11)
+    HDEM_REQUIRE(window <= 11, HDEM_ERR_BAD_ARG, "NaN correction window must be 3..11, got %d",
+                 window);
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     {
         hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)H * W);
-        hipLaunchKernelGGL(correct_nan_kernel, grid2((W + 3) / 4, H), dim3(NT), 0, ctx->stream, dem,
-                           H, W, out);
+        if (window == 3)
+            hipLaunchKernelGGL(correct_nan_kernel, grid2((W + 3) / 4, H), dim3(NT), 0, ctx->stream,
+                               dem, H, W, out);
+        else
+            hipLaunchKernelGGL(correct_nan_ws_kernel, grid2(W, H), dim3(NT), 0, ctx->stream, dem, H,
+                               W, window / 2, out);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
@@ -735,7 +780,7 @@ extern "C" int hdem_lagoons_detection_f32_dev(hdem_ctx *ctx, const float *hsheds
     float *major = (float *)scratch;
     if (!fixed) fixed = (float *)(scratch + fbytes);
     if (!values) values = (float *)(scratch + 2 * fbytes);
-    if (int rc = hdem_correct_nan_f32_dev(ctx, hsheds, H, W, fixed)) return rc;
+    if (int rc = hdem_correct_nan_f32_dev(ctx, hsheds, H, W, 3, fixed)) return rc;
     if (int rc = hdem_majority_f32_dev(ctx, fixed, H, W, 11, major)) return rc;
     if (int rc = tidying(ctx, major, H, W, values, mask)) return rc;
     HDEM_HIP_CHECK(hipGetLastError());

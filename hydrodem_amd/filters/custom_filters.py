@@ -348,16 +348,14 @@ class BlanksFourier(Filter):  # pylint: disable=too-few-public-methods
     """Peaks of a spectrum magnitude: cells above 4x the mean of their 55 x 55
     neighbourhood, its inner 5 x 5 and everything past the array edge left out.
     Returns (mask, image with the peaks zeroed) (custom_filters.py:369-429).
-    The kernel is built for the one window the reference uses, 55."""
+    Any odd window from 7 to 201; 55, the one the reference's pipeline uses, has a
+    kernel instance of its own."""
 
     def __init__(self, *, window_size):
         self.window_size = window_size
 
     def apply(self, image_to_filter):
-        if self.window_size != 55:
-            raise NotImplementedError("BlanksFourier is built for window_size=55 "
-                                      "(the only value the reference uses)")
-        return backend.blanks_fourier(image_to_filter)
+        return backend.blanks_fourier(image_to_filter, self.window_size)
 
 
 class DetectBlanksFourier(Filter):  # pylint: disable=too-few-public-methods
@@ -479,25 +477,24 @@ class MajorityFilter(Filter):  # pylint: disable=too-few-public-methods
 class CorrectNANValues(Filter):  # pylint: disable=too-few-public-methods
     """Voids (cells < 0) become the mean of their non-negative neighbours; like the
     reference (custom_filters.py:260-317) this writes into its input and returns
-    it.  Built for the 3 x 3 window the reference uses."""
+    it.  Odd windows 3 to 11 (the reference's pipeline uses 3)."""
 
     def __init__(self, *, window_size=3):
         self.window_size = window_size
 
     def apply(self, image_to_filter):
-        if self.window_size != 3:
-            raise NotImplementedError("CorrectNANValues is built for window_size=3 "
-                                      "(the only value the reference uses)")
         dem = image_to_filter
         g = np.ascontiguousarray(dem, dtype=np.float32)
-        fixed = backend.correct_nan_dev(backend.DeviceRaster.from_host(g)).to_host()
+        fixed = backend.correct_nan_dev(backend.DeviceRaster.from_host(g),
+                                        window_size=self.window_size).to_host()
+        r = int(self.window_size) // 2
         sel = np.zeros(g.shape, dtype=bool)
-        sel[1:-1, 1:-1] = g[1:-1, 1:-1] < 0
+        sel[r:g.shape[0] - r, r:g.shape[1] - r] = g[r:g.shape[0] - r, r:g.shape[1] - r] < 0
         dem[sel] = fixed[sel]
         return dem
 
     def apply_device(self, raster):
-        return backend.correct_nan_dev(raster)
+        return backend.correct_nan_dev(raster, window_size=self.window_size)
 
 
 class MaskNegatives(ComposedFilter):  # pylint: disable=too-few-public-methods

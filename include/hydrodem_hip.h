@@ -244,9 +244,11 @@ int hdem_fourier_destripe_f32(hdem_ctx *ctx, const float *dem, int H, int W,
                               float *out, uint8_t *mask);
 int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W,
                                   float *out, uint8_t *mask);
-/* BlanksFourier.apply (:400-429), window 55, inner 5, factor 4: found[i] = 1
- * where q > 4 x hollow mean; q is rewritten as q * (1 - found). */
-int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, uint8_t *found);
+/* BlanksFourier.apply (:400-429), `window` odd in 7..201 (the reference's pipeline: 55),
+ * inner 5, factor 4: found[i] = 1 where q > 4 x hollow mean; q is rewritten as
+ * q * (1 - found). */
+int hdem_blanks_fourier_f32_dev(hdem_ctx *ctx, float *q, int h, int w, int window,
+                                uint8_t *found);
 /* IsolatedPoints.apply (:344-366) and ExpandFilter.apply (:103-125) on byte masks. */
 int hdem_isolated_points_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w,
                                 int window, uint8_t *out);
@@ -258,9 +260,11 @@ int hdem_expand_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w, int win
 int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, int inverse);
 
 /* ---- SURVEY 8f-3  HydroSHEDS / lagoon branch --------------------------------
- * CorrectNANValues.apply (custom_filters.py:287-317, window 3): interior cells < 0
- * <- float32 mean of their neighbours >= 0 (NaN when there is none). */
-int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W, float *out);
+ * CorrectNANValues.apply (custom_filters.py:287-317): cells < 0 whose `window` (odd, 3..11;
+ * the reference's pipeline: 3) fits <- float32 mean of the window's other cells >= 0, summed
+ * as NumPy sums them (NaN when there is none). */
+int hdem_correct_nan_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W, int window,
+                             float *out);
 /* MajorityFilter.apply (:44-73): value held by > 70 % of (window^2 - 1) cells of the
  * window minus its corners, else 0; window odd, 3..15. */
 int hdem_majority_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int window,

@@ -681,7 +681,7 @@ def test_c_abi_error_codes_of_the_newer_entry_points():
     assert lib.hdem_binary_erosion_u8_dev(h, m8.ptr, 40, 48, None, 0, 0, 2, None, out.ptr) == backend.BAD_ARG
     assert lib.hdem_grey_dilation_f32_dev(h, z.ptr, 40, 48, 4, 3, out.ptr) == backend.BAD_ARG
     assert lib.hdem_fourier_destripe_f32_dev(h, z.ptr, 40, 48, out.ptr, None) == backend.WINDOW_HIGH
-    assert lib.hdem_blanks_fourier_f32_dev(h, z.ptr, 40, 48, m8.ptr) == backend.WINDOW_HIGH
+    assert lib.hdem_blanks_fourier_f32_dev(h, z.ptr, 40, 48, 55, m8.ptr) == backend.WINDOW_HIGH
     assert lib.hdem_expand_u8_dev(h, m8.ptr, 40, 48, 13, m8.ptr) == backend.BAD_ARG
     assert lib.hdem_memcpy_h2d_async(h, None, None, 16) == backend.BAD_ARG
     p = ctypes.c_void_p()
