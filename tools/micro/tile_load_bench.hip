@@ -75,6 +75,34 @@ __global__ __launch_bounds__(64, 2) void k(const float* __restrict__ z, const fl
                 for (int r = 1; r < 63; ++r) if (y0 + r < H - 1)
                     ((float*)w)[(size_t)(y0 + r) * W + x0 + lane] = a[r] + b[r];
             }
+        } else if (VARIANT == 20 || VARIANT == 30) {   // tile-major blocks (16 KB per tile and array), dword rows, + store
+            float a[64], b[64];
+            const size_t base = (size_t)t * 4096;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) { a[r] = z[base + r * 64 + lane]; b[r] = w[base + r * 64 + lane]; }
+            if (VARIANT == 30) {
+#pragma unroll
+                for (int r = 0; r < 64; ++r) acc += a[r] * b[r];
+            } else {
+#pragma unroll
+                for (int r = 1; r < 63; ++r) ((float*)w)[base + r * 64 + lane] = a[r] + b[r];
+            }
+        } else if (VARIANT == 21 || VARIANT == 31) {   // tile-major, register image: 16 x dwordx4 per array, + store
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4 a[16], b[16];
+            const size_t base = (size_t)t * 4096;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                a[i] = *(const f4*)(z + base + i * 256 + lane * 4);
+                b[i] = *(const f4*)(w + base + i * 256 + lane * 4);
+            }
+            if (VARIANT == 31) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc += a[i].x * b[i].x + a[i].y * b[i].y + a[i].z * b[i].z + a[i].w * b[i].w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) *(f4*)((float*)w + base + i * 256 + lane * 4) = a[i] + b[i];
+            }
         } else {                       // only one array (z), dword
             float a[64];
             const int xc = min(x0 + lane, W - 1);
@@ -97,8 +125,9 @@ int run(const char* name, const float* z, const float* w, float* out, int H, int
         hipLaunchKernelGGL((k<STEP, VARIANT>), dim3(grid), dim3(64), 0, 0, z, w, out, H, W, tiles_x, nt);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        double bytes = (double)nt * 64 * 64 * 4 * (VARIANT == 2 ? 1 : 2);
-        if (rep == 2) printf("%-34s grid %6d: %.3f ms  %.0f GB/s (window bytes)\n", name, grid, ms, bytes / ms / 1e6);
+        const bool stores = VARIANT == 4 || VARIANT == 5 || VARIANT == 20 || VARIANT == 21;
+        double bytes = (double)nt * 64 * 64 * 4 * (VARIANT == 2 ? 1 : stores ? 3 : 2);
+        if (rep == 2) printf("%-34s grid %6d: %.3f ms  %.0f GB/s (window bytes, stores counted as a window)\n", name, grid, ms, bytes / ms / 1e6);
     }
     return 0;
 }
@@ -107,8 +136,9 @@ int main()
 {
     const int H = 16384, W = 16384;
     float *z, *w, *out;
-    CK(hipMalloc(&z, (size_t)H * W * 4)); CK(hipMalloc(&w, (size_t)H * W * 4)); CK(hipMalloc(&out, 64));
-    CK(hipMemset(z, 0, (size_t)H * W * 4)); CK(hipMemset(w, 0, (size_t)H * W * 4));
+    const size_t cells = (size_t)71000 * 4096;   // also holds the tile-major variants
+    CK(hipMalloc(&z, cells * 4)); CK(hipMalloc(&w, cells * 4)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(z, 0, cells * 4)); CK(hipMemset(w, 0, cells * 4));
     for (int grid : {2048, 70225}) {
         run<62, 0>("dword rows, step 62", z, w, out, H, W, grid);
         run<64, 0>("dword rows, step 64 (aligned)", z, w, out, H, W, grid);
@@ -119,6 +149,10 @@ int main()
         run<62, 10>("dword rows, scrambled order", z, w, out, H, W, grid);
         run<62, 4>("sc1 loads + sc1 stores", z, w, out, H, W, grid);
         run<62, 5>("plain loads + plain stores", z, w, out, H, W, grid);
+        run<62, 30>("tile-major dword rows, loads", z, w, out, H, W, grid);
+        run<62, 31>("tile-major dwordx4 image, loads", z, w, out, H, W, grid);
+        run<62, 20>("tile-major dword rows + stores", z, w, out, H, W, grid);
+        run<62, 21>("tile-major dwordx4 + stores", z, w, out, H, W, grid);
     }
     return 0;
 }
