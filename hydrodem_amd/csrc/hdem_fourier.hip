@@ -331,7 +331,6 @@ __global__ __launch_bounds__(NT) void quadrant_abs_kernel(const float2 *__restri
 // the 256 column sums into an inclusive prefix (wave scan by shuffles + the three wave
 // totals) and every output is P[c + R] - P[c - R - 1] -- two LDS reads instead of 55.
 // Out of place: q_out <- q * (1 - hit) (may be NULL: the second pass only needs the mask).
-constexpr int HT = 256;
 
 // Inclusive prefix sum over the 64 lanes of a wave, float64, with DPP lane moves instead
 // of LDS-crossbar shuffles: four shifts inside each row of 16 lanes (lanes without a source
@@ -358,116 +357,180 @@ __device__ __forceinline__ double wave_scan_f64(double p)
     return p;
 }
 
-// RT: half the window, or 0 = taken from `reach` at run time (BlanksFourier windows other
-// than the 55 of the reference's pipeline)
+// Four columns per lane (RT: half the window, or 0 = taken from `reach` at run time --
+// BlanksFourier windows other than the 55 of the reference's pipeline).  Round 1's form held
+// one column per lane and was instruction-bound: ~250 vector instructions per row and wave,
+// most of them per-lane overhead that does not depend on how many cells the lane holds (five
+// row loads, two float64 wave scans, the LDS hand-off).  Here the row loads are 16-byte, the
+// scans run on the lanes' totals (a lane-local prefix in front, the exclusive wave prefix
+// added) and the inner window is a prefix difference too.  128 lanes = 512 columns per block,
+// 512 - 2R of them outputs; one row per barrier, two LDS buffers; the start-up column sums
+// are read eight rows at a time.
+constexpr int H4T = 128, H4W = 4 * H4T;
+
 template <int RT, int r>
-__global__ __launch_bounds__(HT) void hollow_detect_kernel(const float *__restrict__ q, int h, int w,
-                                                           float factor, int seg,
-                                                           float *__restrict__ q_out,
-                                                           uint8_t *found, uint8_t *total,
-                                                           uint8_t *occ_mark,
-                                                           const uint8_t *__restrict__ occ_skip,
-                                                           int occ_w, int reach)
+__global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__restrict__ q, int h, int w,
+                                                             float factor, int seg,
+                                                             float *__restrict__ q_out,
+                                                             uint8_t *found, uint8_t *total,
+                                                             uint8_t *occ_mark,
+                                                             const uint8_t *__restrict__ occ_skip,
+                                                             int occ_w, int reach)
 {
     const int R = RT ? RT : reach;
-    // [buffer][row of the pair]: two rows share a block barrier, two buffers alternate
-    __shared__ double pre[2][2][HT + 1];   // per-wave inclusive prefix of the big column sums
-    __shared__ double sml[2][2][HT];       // small column sums
-    __shared__ double wtot[2][2][HT / 64];
+    __shared__ double pre[2][H4W + 1], sml[2][H4W + 1];   // inclusive prefixes inside each wave; [0] = 0
+    __shared__ double wtot[2][2], wsml[2][2];             // the waves' totals
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = blockIdx.x * (HT - 2 * R) - R + tid;          // my column
+    const int outw = H4W - 2 * R;
+    const int c_first = (int)blockIdx.x * outw - R, c0 = c_first + 4 * tid;
     const int y0 = blockIdx.y * seg, y1 = min(y0 + seg, h);
     if (occ_skip) {
-        // Second pass: a cell can only become a peak now if the first pass zeroed a cell
-        // of its window (else both its value and its mean are what they were, and it was
-        // no peak).  occ_skip marks the 32 x 32 cell blocks that hold first-pass peaks:
-        // nothing within reach of this block's outputs -> nothing to do here.
-        const int c_first = (int)blockIdx.x * (HT - 2 * R) - R;
-        const int c_lo = max(c_first, 0) >> 5, c_hi = min(c_first + HT - 1, w - 1) >> 5;
+        const int c_lo = max(c_first, 0) >> 5, c_hi = min(c_first + H4W - 1, w - 1) >> 5;
         const int r_lo = max(y0 - R, 0) >> 5, r_hi = min(y1 - 1 + R, h - 1) >> 5;
         const int nc = c_hi - c_lo + 1, cells = nc * (r_hi - r_lo + 1);
         int any = 0;
-        for (int k = threadIdx.x; k < cells; k += HT)
+        for (int k = tid; k < cells; k += H4T)
             any |= occ_skip[(size_t)(r_lo + k / nc) * occ_w + c_lo + k % nc];
         if (!__syncthreads_or(any)) return;
     }
-    const bool live = c >= 0 && c < w;
-    const float *col = q + (live ? c : 0);
-    double cb = 0.0, cs = 0.0;
-    if (live) {
-        for (int y = max(y0 - R, 0); y <= min(y0 + R, h - 1); ++y) cb += (double)col[(size_t)y * w];
-        for (int y = max(y0 - r, 0); y <= min(y0 + r, h - 1); ++y) cs += (double)col[(size_t)y * w];
+    if (tid == 0) { pre[0][0] = pre[1][0] = 0.0; sml[0][0] = sml[1][0] = 0.0; }
+    const bool all4 = c0 >= 0 && c0 + 3 < w;
+    bool live[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) live[k] = c0 + k >= 0 && c0 + k < w;
+    // one row of my four columns (0 where the column or the row does not exist)
+    auto load4 = [&](int y, bool want) -> hdem_f4 {
+        hdem_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!want || y < 0 || y >= h) return v;
+        const float *row = q + (size_t)y * w;
+        if (all4) return hdem_ld4u(row + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k]) v[k] = row[c0 + k];
+        return v;
+    };
+    // the column sums of the first row's windows: eight row loads in flight at a time (one at
+    // a time, each waited for, this start-up was a third of the kernel), added in row order
+    double cb[4] = {0.0, 0.0, 0.0, 0.0}, cs[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ya = max(y0 - R, 0), ye = min(y0 + R, h - 1); ya <= ye; ya += 8) {
+        hdem_f4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = load4(ya + j, ya + j <= ye);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cb[k] += (double)v[j][k];
     }
-    const bool outputs = tid >= R && tid < HT - R && live;
-    const int cols_b = min(c + R, w - 1) - max(c - R, 0) + 1;
-    const int cols_s = min(c + r, w - 1) - max(c - r, 0) + 1;
-    // UN rows per trip: their loads (4 sliding-sum rows + the cell itself, per row) are all
-    // issued before the first scan, so the block-wide barriers of a row overlap the memory
-    // latency of the next ones instead of adding to it.
-    constexpr int UN = 4;
+    {
+        hdem_f4 v[2 * r + 1];
+#pragma unroll
+        for (int j = 0; j < 2 * r + 1; ++j) v[j] = load4(y0 - r + j, y0 - r + j <= min(y0 + r, h - 1));
+#pragma unroll
+        for (int j = 0; j < 2 * r + 1; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs[k] += (double)v[j][k];
+    }
+    bool outs[4];
+    int cols_b[4], cols_s[4];
+    bool any_out = false, all_out = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * tid + k, c = c0 + k;
+        outs[k] = i >= R && i < H4W - R && live[k];
+        any_out = any_out || outs[k];
+        all_out = all_out && outs[k];
+        cols_b[k] = min(c + R, w - 1) - max(c - R, 0) + 1;
+        cols_s[k] = min(c + r, w - 1) - max(c - r, 0) + 1;
+    }
+    // (Issuing the next rows' loads before working on the current ones -- software pipelining
+    // at 180 registers and two waves per SIMD -- is slower than this form at three: 0.37
+    // against 0.28 ms per launch.)
+    constexpr int UN = 2;
     for (int yb = y0; yb < y1; yb += UN) {
-        float in_b[UN], out_b[UN], in_s[UN], out_s[UN], cell[UN];
+        hdem_f4 in_b[UN], out_b[UN], in_s[UN], out_s[UN], cell[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int y = yb + u;
-            in_b[u] = (live && y + R + 1 < h) ? col[(size_t)(y + R + 1) * w] : 0.0f;
-            out_b[u] = (live && y - R >= 0 && y < h) ? col[(size_t)(y - R) * w] : 0.0f;
-            in_s[u] = (live && y + r + 1 < h) ? col[(size_t)(y + r + 1) * w] : 0.0f;
-            out_s[u] = (live && y - r >= 0 && y < h) ? col[(size_t)(y - r) * w] : 0.0f;
-            cell[u] = (outputs && y < y1) ? col[(size_t)y * w] : 0.0f;
+            in_b[u] = load4(y + R + 1, true);
+            out_b[u] = load4(y - R, y < h);
+            in_s[u] = load4(y + r + 1, true);
+            out_s[u] = load4(y - r, y < h);
+            cell[u] = load4(y, any_out && y < y1);
         }
 #pragma unroll
-        for (int u = 0; u < UN; u += 2) {
+        for (int u = 0; u < UN; ++u) {
             const int y = yb + u;
-            if (y >= y1) break;                                   // uniform over the block
-            const int buf = (u >> 1) & 1;
-            // Two rows per block barrier: their column sums are known up front (the loads are
-            // in), so the two scan chains interleave.  Inclusive scan of the sums inside each
-            // wave; the block-wide prefix of column i is that plus the totals of the waves
-            // before i's, added by the reader.
-            const double cb1 = cb + ((double)in_b[u] - (double)out_b[u]);
-            const double cs1 = cs + ((double)in_s[u] - (double)out_s[u]);
-            const double p0 = wave_scan_f64(cb), p1 = wave_scan_f64(cb1);
-            if (lane == 63) { wtot[buf][0][wave] = p0; wtot[buf][1][wave] = p1; }
-            pre[buf][0][tid + 1] = p0;
-            pre[buf][1][tid + 1] = p1;
-            sml[buf][0][tid] = cs;
-            sml[buf][1][tid] = cs1;
+            if (y >= y1) break;                               // uniform over the block
+            const int buf = u & 1;
+            // lane-local inclusive prefixes, then the wave's exclusive prefix of the lane totals
+            double lb[4], ls[4];
+            lb[0] = cb[0]; ls[0] = cs[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { lb[k] = lb[k - 1] + cb[k]; ls[k] = ls[k - 1] + cs[k]; }
+            const double pb = wave_scan_f64(lb[3]), ps = wave_scan_f64(ls[3]);
+            const double eb = pb - lb[3], es = ps - ls[3];
+            if (lane == 63) { wtot[buf][wave] = pb; wsml[buf][wave] = ps; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pre[buf][1 + 4 * tid + k] = eb + lb[k];
+                sml[buf][1 + 4 * tid + k] = es + ls[k];
+            }
             __syncthreads();
-            if (outputs) {
-                const int a = tid + R, b = tid - R - 1;          // window = columns b+1 .. a
-                const int wa = a >> 6, wb = b >> 6;
+            if (any_out) {
+                const double t0 = wtot[buf][0], u0 = wsml[buf][0];
+                const int rows_b = min(y + R, h - 1) - max(y - R, 0) + 1;
+                const int rows_s = min(y + r, h - 1) - max(y - r, 0) + 1;
+                unsigned hits = 0;
+                float keep[4];
 #pragma unroll
-                for (int v2 = 0; v2 < 2; ++v2) {
-                    const int yy = y + v2;
-                    if (yy >= y1) break;
-                    const double t1 = wtot[buf][v2][0], t2 = t1 + wtot[buf][v2][1],
-                                 t3 = t2 + wtot[buf][v2][2];
-                    const double hi = pre[buf][v2][a + 1] +
-                                      (wa == 0 ? 0.0 : wa == 1 ? t1 : wa == 2 ? t2 : t3);
-                    const double lo = b < 0 ? 0.0
-                                            : pre[buf][v2][b + 1] +
-                                                  (wb == 0 ? 0.0 : wb == 1 ? t1 : wb == 2 ? t2 : t3);
-                    const double sb = hi - lo;
-                    double ss = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 4 * tid + k;
+                    // window = columns b+1 .. a of the block; a column >= 256 sits in wave 1
+                    const int a = min(i + R, H4W - 1), b = max(i - R - 1, -1);
+                    const int a2 = min(i + r, H4W - 1), b2 = max(i - r - 1, -1);
+                    const double hi = pre[buf][a + 1] + (a >= 256 ? t0 : 0.0);
+                    const double lo = pre[buf][b + 1] + (b >= 256 ? t0 : 0.0);
+                    const double hs = sml[buf][a2 + 1] + (a2 >= 256 ? u0 : 0.0);
+                    const double lw = sml[buf][b2 + 1] + (b2 >= 256 ? u0 : 0.0);
+                    const double sb = hi - lo, ss = hs - lw;
+                    const int cnt = rows_b * cols_b[k] - rows_s * cols_s[k];
+                    const float v = cell[u][k];
+                    const bool hit = outs[k] && cnt > 0 &&
+                                     (double)v * (double)cnt > (double)factor * (sb - ss);
+                    hits |= (unsigned)hit << k;
+                    keep[k] = hit ? v * 0.0f : v;
+                }
+                const size_t o = (size_t)y * w + c0;
+                if (all_out) {
+                    if (found) {
+                        // (4 bytes at any alignment: one unaligned dword store)
+                        typedef unsigned u1 __attribute__((aligned(1)));
+                        *reinterpret_cast<u1 *>(found + o) =
+                            (hits & 1u) | (hits & 2u) << 7 | (hits & 4u) << 14 | (hits & 8u) << 21;
+                    }
+                    if (q_out) hdem_st4u(q_out + o, (hdem_f4){keep[0], keep[1], keep[2], keep[3]});
+                } else {
 #pragma unroll
-                    for (int k = -r; k <= r; ++k) ss += sml[buf][v2][tid + k];
-                    const int rows_b = min(yy + R, h - 1) - max(yy - R, 0) + 1;
-                    const int rows_s = min(yy + r, h - 1) - max(yy - r, 0) + 1;
-                    const int cnt = rows_b * cols_b - rows_s * cols_s;
-                    const size_t o = (size_t)yy * w + c;
-                    const float v = cell[u + v2];
-                    // q > factor * sum / cnt as q * cnt > factor * sum: no float64 division
-                    // per cell (nanmean of an empty window is NaN and compares false: cnt > 0)
-                    const bool hit = cnt > 0 && (double)v * (double)cnt > (double)factor * (sb - ss);
-                    if (found) found[o] = hit ? 1 : 0;
-                    if (occ_mark && hit) occ_mark[(size_t)(yy >> 5) * occ_w + (c >> 5)] = 1;
-                    if (total && hit) total[o] = (uint8_t)(total[o] + 1);
-                    if (q_out) q_out[o] = hit ? v * 0.0f : v;
+                    for (int k = 0; k < 4; ++k) {
+                        if (!outs[k]) continue;
+                        if (found) found[o + k] = (hits >> k) & 1u;
+                        if (q_out) q_out[o + k] = keep[k];
+                    }
+                }
+                if (hits) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!((hits >> k) & 1u)) continue;
+                        if (occ_mark) occ_mark[(size_t)(y >> 5) * occ_w + ((c0 + k) >> 5)] = 1;
+                        if (total) total[o + k] = (uint8_t)(total[o + k] + 1);
+                    }
                 }
             }
-            cb = cb1 + ((double)in_b[u + 1] - (double)out_b[u + 1]);
-            cs = cs1 + ((double)in_s[u + 1] - (double)out_s[u + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cb[k] += (double)in_b[u][k] - (double)out_b[u][k];
+                cs[k] += (double)in_s[u][k] - (double)out_s[u][k];
+            }
         }
     }
 }
@@ -710,21 +773,24 @@ int blanks_pass(hdem_ctx *ctx, const float *q, int h, int w, float *q_out, uint8
                 uint8_t *total, uint8_t *occ_mark = nullptr, const uint8_t *occ_skip = nullptr,
                 int window = 55)
 {
-    // rows one block walks: long runs amortise the 2R-row start-up of the sliding sums,
-    // short ones fill the chip on small quadrants (aim for >= 2048 blocks of 4 waves)
-    const int R = window / 2, per_block = HT - 2 * R;
-    const int bx = (w + per_block - 1) / per_block;
-    int seg = 256;
-    while (seg > 32 && (int64_t)bx * ((h + seg - 1) / seg) < 2048) seg /= 2;
+    const int R = window / 2;
+    const int per_block4 = H4W - 2 * R, bx4 = (w + per_block4 - 1) / per_block4;
+    // rows one block walks.  A block's rows are a serial chain (scan, barrier, LDS, ~2.6 us per
+    // row with three waves per SIMD sharing the issue slots), so what counts is the number of
+    // chains: the launch takes 0.22 ms + 1.8 us per row of a block at 8182^2 -- 0.27 ms at 32
+    // rows, 0.33 at 64, 0.68 at 256 -- although a short block reads its 2R start-up rows for few
+    // outputs (0.31 ms at 16 rows).
+    int seg4 = 256;
+    while (seg4 > 32 && (int64_t)bx4 * ((h + seg4 - 1) / seg4) < 4096) seg4 /= 2;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_FOURIER_DETECT, (int64_t)h * w);
-        const dim3 grid(bx, (h + seg - 1) / seg);
+        const dim3 grid(bx4, (h + seg4 - 1) / seg4);
         if (window == 55)
-            hipLaunchKernelGGL((hollow_detect_kernel<27, 2>), grid, dim3(HT), 0, ctx->stream, q, h,
-                               w, 4.0f, seg, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, 27);
+            hipLaunchKernelGGL((hollow_detect4_kernel<27, 2>), grid, dim3(H4T), 0, ctx->stream, q, h,
+                               w, 4.0f, seg4, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, 27);
         else
-            hipLaunchKernelGGL((hollow_detect_kernel<0, 2>), grid, dim3(HT), 0, ctx->stream, q, h, w,
-                               4.0f, seg, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, R);
+            hipLaunchKernelGGL((hollow_detect4_kernel<0, 2>), grid, dim3(H4T), 0, ctx->stream, q, h,
+                               w, 4.0f, seg4, q_out, found, total, occ_mark, occ_skip, (w + 31) / 32, R);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
