@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT) void groves_kernel(const float *__restrict__ im
 
 // ---------------------------------------------------------------------------
 // Streaming form of the same arithmetic (used for ws <= 15).  One WAVE owns a
-// 256-column x 128-row strip and walks down its input rows once:
+// 256-column strip of 96..192 rows (launch_ws picks the height) and walks down its input rows once:
 //   * lane l holds columns 4l..4l+3 as one float4 (a wave-level load is 1 KiB of
 //     one raster row); lanes 0..2p-1 also fetch one halo column each; rows are
 //     prefetched three ahead so ~3 KiB per wave are always in flight;
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(NT) void groves_kernel(const float *__restrict__ im
 //   * the row sums R0/R2 feed a ring of `ws` vertical accumulators per column held
 //     in registers (slot = output row mod ws, static after unrolling by ws): the
 //     output row that receives its last term is finished, blended and stored.
-// HBM reads are the raster once plus (128+2p)/128 row overlap (1.11x at ws = 15)
+// HBM reads are the raster once plus (rows+2p)/rows row overlap (~1.1x at ws = 15)
 // instead of the 1.75x of the tiled kernel; no tile is staged twice.
 // ---------------------------------------------------------------------------
 constexpr int SW_COLS = 256;     // strip width  (cells) = 64 lanes x 4
-constexpr int SR_ROWS = 128;     // strip height (output rows)
+constexpr int SR_ROWS = 128;     // strip height (output rows) unless the launch picks another
 
 // (at least 3 waves per SIMD: ws = 15 then fits 168 registers with 5 of them spilled,
 // and runs 6 % faster than at 183 registers and 2 waves)
@@ -168,7 +168,7 @@ template <int WS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void groves_stream_kernel(const float *__restrict__ img,
                                                           const uint8_t *__restrict__ groves,
                                                           int H, int W, float thr,
-                                                          int strips_x, int nstrips,
+                                                          int strips_x, int nstrips, int strip_rows,
                                                           quad_coef cf, float *__restrict__ out)
 {
     constexpr int P = WS / 2;
@@ -186,12 +186,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
     const int strip = blockIdx.x * 4 + wave;
     if (strip >= nstrips) return;
     const int sy = strip / strips_x, sx = strip - sy * strips_x;
-    const int x0 = sx * SW_COLS, y0 = sy * SR_ROWS;
+    const int x0 = sx * SW_COLS, y0 = sy * strip_rows;
     const int x = x0 + 4 * lane;
     float *rb = &rows[wave][0][0];
     const bool vec_ok = x + 4 <= W;
 
-    float c0 = img[(size_t)min(y0 + SR_ROWS / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
+    float c0 = img[(size_t)min(y0 + strip_rows / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
     if (!(fabsf(c0) < HDEM_INF)) c0 = 0.0f;
 
     // halo column of this lane (lanes 0..2p-1): left halo x0-p+lane, right x0+256+(lane-p)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
 #pragma unroll
     for (int k = 0; k < PF; ++k) { load_row(k, pre[k], preh[k]); preg[k] = load_mask(k); }
 
-    constexpr int NROWS = SR_ROWS + 2 * P;
+    const int NROWS = strip_rows + 2 * P;
     for (int base = 0; base < NROWS; base += WS) {
 #pragma unroll
         for (int u = 0; u < WS; ++u) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
             // ---- output row i - 2p is complete: blend and store ------------------------
             const int done = (u + 1) % WS;            // slot of output row i - (WS - 1)
             const int oy = i - 2 * P, y = y0 + oy;
-            if (oy >= 0 && oy < SR_ROWS && y < H && x < W) {
+            if (oy >= 0 && oy < strip_rows && y < H && x < W) {
                 const size_t gi = (size_t)y * W + x;
                 float o4[4];
                 // the centre row of this output (input row i - p) is still in the ring, raw
@@ -377,10 +377,24 @@ void launch_ws(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, in
                float thr, const quad_coef &cf, float *out)
 {
     if constexpr (WS == 15 || WS == 9 || WS == 3) {      // streaming form (prefetch ring | ws)
-        const int sx = (W + SW_COLS - 1) / SW_COLS, sy = (H + SR_ROWS - 1) / SR_ROWS;
-        const int n = sx * sy;
+        // Strip height: every strip is one wave's serial walk, and the machine holds 12 of them
+        // per CU (three waves per SIMD) -- a count of strips just above a multiple of that leaves
+        // the last round nearly empty (16384^2 at 128 rows: 8192 strips on 3072 places, 2.67
+        // rounds).  Among the heights from 96 to 192 rows take the one whose last round is
+        // fullest, ties to the taller (less overlap between strips).
+        const int sx = (W + SW_COLS - 1) / SW_COLS, places = ctx->num_cus * 12;
+        int rows = SR_ROWS;
+        double best = -1.0;
+        for (int cand = 96; cand <= 192; ++cand) {
+            const int64_t strips = (int64_t)sx * ((H + cand - 1) / cand);
+            const int64_t rounds = (strips + places - 1) / places;
+            // useful share of the machine-time: work / (rounds x places x strip length)
+            const double eff = (double)H * sx / ((double)rounds * places * (cand + 2 * (WS / 2)));
+            if (eff >= best) { best = eff; rows = cand; }
+        }
+        const int sy = (H + rows - 1) / rows, n = sx * sy;
         hipLaunchKernelGGL(groves_stream_kernel<WS>, dim3((n + 3) / 4), dim3(NT), 0, ctx->stream,
-                           img, groves, H, W, thr, sx, n, cf, out);
+                           img, groves, H, W, thr, sx, n, rows, cf, out);
         return;
     }
     int tx = (W + GTW - 1) / GTW, ty = (H + GTH - 1) / GTH;
