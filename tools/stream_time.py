@@ -12,7 +12,7 @@ for rep in range(2):
     t = time.time(); a = B.groves(img, mask, iterations=3); dt = time.time() - t
     print(f"whole-array host call: {dt*1e3:.1f} ms -> {n*n/dt/1e6:.0f} Mcells/s")
 out = np.empty_like(img)
-for depth in (1, 2, 3):
+for depth in (1, 2, 3, 4, 6, 8):
     with S.BandStream(img.shape, band_rows=band, depth=depth, **S.groves_op(3)) as bs:
         for rep in range(2):
             t = time.time(); bs.run([img, mask], out); dt = time.time() - t
