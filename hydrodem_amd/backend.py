@@ -12,6 +12,7 @@ import importlib.util
 import os
 import sys
 import threading
+import weakref
 
 import numpy as np
 
@@ -269,6 +270,74 @@ _DTYPES = {np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.uint8),
            np.dtype(np.complex64)}
 
 
+class _HostBlocks:
+    """Page-locked host memory for the arrays the host entry points return.
+
+    A result that comes back into a fresh ``np.empty`` pays for its pages three times: the
+    faults when they are first written (taken on 16 threads by the library, still ~10 ms per
+    GiB), a device-to-host copy that stages through the driver at 40 instead of 56 GB/s, and
+    ~50 ms per GiB of unmapping when the array is dropped -- more than the kernels and the
+    bus together for every operator here.  Results of 32 MiB and more are therefore NumPy
+    arrays over page-locked blocks that return here when the array (and every view of it)
+    has gone, and are handed out again for the next result of that size.  The cache is capped
+    (``HDEM_HOST_POOL_MIB``, default 8 GiB; 0 = plain ``np.empty``); blocks beyond it are
+    unlocked and freed at once."""
+
+    MIN_BYTES = 32 << 20
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.spare = {}                      # nbytes -> [address, ...]
+        self.cached = 0
+        mib = os.environ.get("HDEM_HOST_POOL_MIB")
+        self.cap = (int(mib) << 20) if mib is not None else (8 << 30)
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64))
+        nbytes = count * dtype.itemsize
+        if nbytes < self.MIN_BYTES or self.cap <= 0:
+            return np.empty(shape, dtype)
+        try:
+            ctx = context()
+            with self.lock:
+                stack = self.spare.get(nbytes)
+                addr = stack.pop() if stack else None
+                if addr is not None:
+                    self.cached -= nbytes
+            if addr is None:
+                ptr = ctypes.c_void_p()
+                if ctx.lib.hdem_host_alloc(ctx.handle, nbytes, ctypes.byref(ptr)) != 0 or not ptr.value:
+                    return np.empty(shape, dtype)
+                addr = ptr.value
+            buf = (ctypes.c_char * nbytes).from_address(addr)
+            root = np.frombuffer(buf, dtype=dtype, count=count)
+            weakref.finalize(root, self._give_back, addr, nbytes)
+            return root.reshape(shape)
+        except Exception:  # pylint: disable=broad-except
+            return np.empty(shape, dtype)
+
+    def _give_back(self, addr, nbytes):
+        try:
+            with self.lock:
+                if self.cached + nbytes <= self.cap:
+                    self.spare.setdefault(nbytes, []).append(addr)
+                    self.cached += nbytes
+                    return
+            ctx = context()
+            ctx.lib.hdem_host_free(ctx.handle, ctypes.c_void_p(addr))
+        except Exception:  # pylint: disable=broad-except
+            pass                                 # (interpreter shutdown: the process is going)
+
+
+_host_blocks = _HostBlocks()
+
+
+def host_empty(shape, dtype):
+    """An uninitialised host array for a result of the library (see :class:`_HostBlocks`)."""
+    return _host_blocks.empty(shape, dtype)
+
+
 class DeviceRaster:
     """A 2-D raster resident in HBM (owning unless wrapped)."""
 
@@ -312,7 +381,7 @@ class DeviceRaster:
                    keepalive=keepalive)
 
     def to_host(self):
-        out = np.empty(self.shape, dtype=self.dtype)
+        out = host_empty(self.shape, self.dtype)
         self.ctx.check(self.ctx.lib.hdem_memcpy_d2h(self.ctx.handle,
                                                     out.ctypes.data, self.ptr,
                                                     out.nbytes))
@@ -658,7 +727,7 @@ def _host2d(a, dtype):
 def d8(z):
     c = context()
     z = _host2d(z, np.float32)
-    out = np.empty(z.shape, np.uint8)
+    out = host_empty(z.shape, np.uint8)
     c.check(c.lib.hdem_d8_f32(c.handle, z.ctypes.data, z.shape[0], z.shape[1],
                               out.ctypes.data))
     return out
@@ -667,7 +736,7 @@ def d8(z):
 def sinkfill(z, eps=0.0, max_rounds=0, return_stats=False):
     c = context()
     z = _host2d(z, np.float32)
-    out = np.empty_like(z)
+    out = host_empty(z.shape, z.dtype)
     st = FillStats()
     c.check(c.lib.hdem_sinkfill_f32(c.handle, z.ctypes.data, z.shape[0], z.shape[1],
                                     float(eps), int(max_rounds), out.ctypes.data,
@@ -683,7 +752,7 @@ def boxmean3(x, do_round=True):
     else:
         x = _host2d(x, np.float64)
         fn = c.lib.hdem_boxmean3_f64
-    out = np.empty_like(x)
+    out = host_empty(x.shape, x.dtype)
     c.check(fn(c.handle, x.ctypes.data, x.shape[0], x.shape[1], int(bool(do_round)),
                out.ctypes.data))
     return out
@@ -693,7 +762,7 @@ def convolve(x, weights):
     c = context()
     x = _host2d(x, np.float32)
     w = _host2d(weights, np.float64)
-    out = np.empty_like(x)
+    out = host_empty(x.shape, x.dtype)
     c.check(c.lib.hdem_convolve_f32(c.handle, x.ctypes.data, x.shape[0], x.shape[1],
                                     w.ctypes.data, w.shape[0], w.shape[1],
                                     out.ctypes.data))
@@ -706,7 +775,7 @@ def around(x):
         a, fn = np.ascontiguousarray(x, dtype=np.float32), c.lib.hdem_around_f32
     else:
         a, fn = np.ascontiguousarray(x, dtype=np.float64), c.lib.hdem_around_f64
-    out = np.empty_like(a)
+    out = host_empty(a.shape, a.dtype)
     if a.size:
         c.check(fn(c.handle, a.ctypes.data, a.size, out.ctypes.data))
     return out
@@ -715,7 +784,7 @@ def around(x):
 def quadratic(dem, window_size=15):
     c = context()
     dem = _host2d(dem, np.float32)
-    out = np.empty_like(dem)
+    out = host_empty(dem.shape, dem.dtype)
     c.check(c.lib.hdem_quadratic_f32(c.handle, dem.ctypes.data, dem.shape[0],
                                      dem.shape[1], int(window_size), out.ctypes.data),
             window=window_size, shape=dem.shape)
@@ -725,8 +794,8 @@ def quadratic(dem, window_size=15):
 def fourier_destripe(dem, return_mask=False):
     c = context()
     dem = _host2d(dem, np.float32)
-    out = np.empty_like(dem)
-    mask = np.empty(dem.shape, dtype=np.uint8) if return_mask else None
+    out = host_empty(dem.shape, dem.dtype)
+    mask = host_empty(dem.shape, np.uint8) if return_mask else None
     quarter = (dem.shape[0] // 2 - 10, dem.shape[1] // 2 - 10)
     c.check(c.lib.hdem_fourier_destripe_f32(c.handle, dem.ctypes.data, dem.shape[0],
                                             dem.shape[1], out.ctypes.data,
@@ -759,13 +828,23 @@ def fft2(x, inverse=False):
     return d / np.float32(a.size) if inverse else d
 
 
+def mask_bytes(groves_class):
+    """The class raster as the bytes the groves kernel reads (non-zero = grove).  One-byte
+    dtypes go as they are -- at 16384^2 a ``!= 0`` and an ``astype`` are 100 ms of NumPy
+    in front of 2 ms of kernels."""
+    g = np.asarray(groves_class)
+    if g.dtype in (np.uint8, np.bool_, np.int8):
+        return _host2d(g, g.dtype).view(np.uint8)
+    return _host2d(np.not_equal(g, 0), np.bool_).view(np.uint8)
+
+
 def groves(img, groves_class, window_size=15, threshold=1.5, iterations=1):
     c = context()
     img = _host2d(img, np.float32)
-    g = _host2d(np.asarray(groves_class) != 0, np.uint8)
+    g = mask_bytes(groves_class)
     if g.shape != img.shape:
         raise ValueError(f"groves class shape {g.shape} != image shape {img.shape}")
-    out = np.empty_like(img)
+    out = host_empty(img.shape, img.dtype)
     c.check(c.lib.hdem_groves_f32(c.handle, img.ctypes.data, g.ctypes.data,
                                   img.shape[0], img.shape[1], int(window_size),
                                   float(threshold), int(iterations), out.ctypes.data),

@@ -1,6 +1,8 @@
 // Context, memory, error and profiling plumbing of libhydrodem_hip.so.
 #include "hdem_internal.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -231,6 +233,14 @@ static void prefault_host(void *dst, size_t bytes)
     unsigned nthreads = std::thread::hardware_concurrency();
     nthreads = nthreads ? (nthreads > 16 ? 16 : nthreads) : 4;
     char *base = static_cast<char *>(dst);
+    {
+        // 2 MiB pages where the host hands them out on request: 512 x fewer faults here, and
+        // the unmapping of the array when its owner drops it (50 ms per GiB in 4 KiB pages)
+        // shrinks with them.  Whole pages inside the range only; a refusal changes nothing.
+        const uintptr_t lo = ((uintptr_t)base + PAGE - 1) & ~(uintptr_t)(PAGE - 1);
+        const uintptr_t hi = ((uintptr_t)base + bytes) & ~(uintptr_t)(PAGE - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    }
     const size_t per = (bytes / nthreads + PAGE - 1) / PAGE * PAGE;
     std::vector<std::thread> pool;
     try {

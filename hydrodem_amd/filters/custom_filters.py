@@ -119,8 +119,14 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
 
     @staticmethod
     def _is_mask(groves_class):
+        """Only 0 and 1 in the class raster (then the fused kernel's `class != 0` is the
+        reference's product with the class)."""
         g = np.asarray(groves_class)
-        return g.dtype == bool or not np.any((g != 0) & (g != 1))
+        if g.dtype == bool or g.size == 0:
+            return True
+        if g.dtype.kind in "ui":                       # one or two SIMD passes, no temporaries
+            return bool(g.max() <= 1 and (g.dtype.kind == "u" or g.min() >= 0))
+        return not np.any((g != 0) & (g != 1))
 
     def apply(self, image_to_filter):
         Filter.apply(self, image_to_filter)
@@ -147,7 +153,7 @@ class GrovesCorrection(ComposedFilter):  # pylint: disable=too-few-public-method
         groves_class, window, thr = self._params()
         if not self._is_mask(groves_class):
             raise NotImplementedError("the fused groves kernel takes a 0 / 1 class raster")
-        with backend.DeviceRaster.from_host(np.asarray(groves_class) != 0,
+        with backend.DeviceRaster.from_host(backend.mask_bytes(groves_class),
                                             dtype=np.uint8, ctx=raster.ctx) as g:
             out = backend.groves_dev(raster, g, window, thr, 1)
             raster.ctx.synchronize()
@@ -194,7 +200,7 @@ class GrovesCorrectionsIter(ComposedFilter):  # pylint: disable=too-few-public-m
         if params is None:
             return ComposedFilter.apply_device(self, raster)
         groves_class, window, thr = params
-        with backend.DeviceRaster.from_host(np.asarray(groves_class) != 0,
+        with backend.DeviceRaster.from_host(backend.mask_bytes(groves_class),
                                             dtype=np.uint8, ctx=raster.ctx) as g:
             out = backend.groves_dev(raster, g, window, thr, len(self.filters))
             raster.ctx.synchronize()

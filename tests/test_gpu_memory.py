@@ -75,3 +75,31 @@ def test_the_cache_can_be_switched_off(built):
     # (with the cache off the block goes back to the driver; whether hipMalloc returns the same
     # address again is the driver's business -- the call just has to work)
     assert out.stdout.strip() in ("same", "other")
+
+
+def test_large_results_come_back_in_reused_page_locked_blocks(built):
+    """Host results of 32 MiB and more are NumPy arrays over page-locked blocks that return
+    to the library when the array and all its views have gone (backend._HostBlocks)."""
+    import gc
+    z = oracle.synth_dem(3000, 3000)                       # 36 MB
+    zd = backend.DeviceRaster.from_host(z)
+    a = zd.to_host()
+    assert type(a) is np.ndarray and a.flags.writeable and np.array_equal(a, z)
+    addr = a.ctypes.data
+    view = a[100:200]
+    del a
+    gc.collect()
+    b = zd.to_host()                                       # the view keeps the block
+    assert b.ctypes.data != addr and np.array_equal(view, z[100:200])
+    del view
+    gc.collect()
+    c = zd.to_host()
+    assert c.ctypes.data == addr and np.array_equal(c, z)
+    small = backend.DeviceRaster.from_host(z[:100]).to_host()      # below the threshold: np.empty
+    assert np.array_equal(small, z[:100])
+    # an operator's host form returns such an array too, and it behaves like any other
+    d = backend.d8(c_oracle.sinkfill_pflood(z))
+    assert d.dtype == np.uint8 and d.sum() > 0
+    d2 = d.copy()
+    d[:] = 0
+    assert d2.sum() > 0
