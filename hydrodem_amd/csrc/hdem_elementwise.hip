@@ -4,8 +4,8 @@
 // orchestration composes directly (`hydro_dem_process.py:60-91`: mask addition, 1 - mask,
 // two products, then the three-term sum in front of PostProcessingFinal, `:148-149`).
 //
-// One kernel: out[i] = op(image[i], operand[i] or scalar).  Rasters are float32, float64 or
-// uint8 (masks); the arithmetic is done in double -- what NumPy does for the float64 rasters
+// One kernel: out[i] = op(image[i], operand[i] or scalar).  Rasters are float32, float64,
+// uint8 (masks) or int64 (what NumPy makes of `mask * 1`; exact below 2^53); the arithmetic is done in double -- what NumPy does for the float64 rasters
 // the pipeline holds at that point (float32 * int64 promotes), exact for float32 and mask
 // inputs -- and stored in the type the caller asks for.  HBM-bound: 4 cells per lane, one
 // vector load per operand.
@@ -32,6 +32,9 @@ __device__ __forceinline__ void load4(const void *p, int type, int64_t i, int64_
         } else if (type == HDEM_T_F64) {
             const double *d = static_cast<const double *>(p) + i;
             v[0] = d[0]; v[1] = d[1]; v[2] = d[2]; v[3] = d[3];
+        } else if (type == HDEM_T_I64) {
+            const int64_t *d = static_cast<const int64_t *>(p) + i;
+            v[0] = (double)d[0]; v[1] = (double)d[1]; v[2] = (double)d[2]; v[3] = (double)d[3];
         } else {
             const uint8_t *b = static_cast<const uint8_t *>(p) + i;
             v[0] = b[0]; v[1] = b[1]; v[2] = b[2]; v[3] = b[3];
@@ -42,6 +45,7 @@ __device__ __forceinline__ void load4(const void *p, int type, int64_t i, int64_
         const int64_t j = i + k < n ? i + k : n - 1;
         v[k] = type == HDEM_T_F32   ? (double)static_cast<const float *>(p)[j]
                : type == HDEM_T_F64 ? static_cast<const double *>(p)[j]
+               : type == HDEM_T_I64 ? (double)static_cast<const int64_t *>(p)[j]
                                     : (double)static_cast<const uint8_t *>(p)[j];
     }
 }
@@ -71,11 +75,12 @@ __global__ __launch_bounds__(NT) void elementwise_kernel(ew_args a)
         if (i + k >= a.n) break;
         if (a.out_type == HDEM_T_F32) static_cast<float *>(a.out)[i + k] = (float)r[k];
         else if (a.out_type == HDEM_T_F64) static_cast<double *>(a.out)[i + k] = r[k];
+        else if (a.out_type == HDEM_T_I64) static_cast<int64_t *>(a.out)[i + k] = (int64_t)r[k];
         else static_cast<uint8_t *>(a.out)[i + k] = (uint8_t)r[k];
     }
 }
 
-bool known_type(int t) { return t == HDEM_T_F32 || t == HDEM_T_F64 || t == HDEM_T_U8; }
+bool known_type(int t) { return t >= HDEM_T_F32 && t <= HDEM_T_I64; }
 
 }  // namespace
 

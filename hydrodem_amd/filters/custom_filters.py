@@ -474,7 +474,7 @@ class MajorityFilter(Filter):  # pylint: disable=too-few-public-methods
     def apply(self, image_to_filter):
         img = backend.DeviceRaster.from_host(
             np.ascontiguousarray(image_to_filter, dtype=np.float32))
-        return backend.majority_dev(img, self.window_size).to_host().astype(np.float64)
+        return backend.widened_to_host(backend.majority_dev(img, self.window_size), np.float64)
 
     def apply_device(self, raster):
         return backend.majority_dev(raster, self.window_size)
@@ -492,11 +492,17 @@ class CorrectNANValues(Filter):  # pylint: disable=too-few-public-methods
         dem = image_to_filter
         g = np.ascontiguousarray(dem, dtype=np.float32)
         fixed = backend.correct_nan_dev(backend.DeviceRaster.from_host(g),
-                                        window_size=self.window_size).to_host()
+                                        window_size=self.window_size)
+        if g is dem:
+            # (every cell that is not repaired comes back bit for bit)
+            fixed.ctx.check(fixed.ctx.lib.hdem_memcpy_d2h(fixed.ctx.handle, g.ctypes.data,
+                                                          fixed.ptr, g.nbytes))
+            return dem
         r = int(self.window_size) // 2
-        sel = np.zeros(g.shape, dtype=bool)
-        sel[r:g.shape[0] - r, r:g.shape[1] - r] = g[r:g.shape[0] - r, r:g.shape[1] - r] < 0
-        dem[sel] = fixed[sel]
+        sel = g < 0
+        sel[:r] = sel[g.shape[0] - r:] = False
+        sel[:, :r] = sel[:, g.shape[1] - r:] = False
+        np.copyto(dem, fixed.to_host(), where=sel, casting="unsafe")
         return dem
 
     def apply_device(self, raster):
@@ -567,13 +573,20 @@ class LagoonsDetection(ComposedFilterResults):  # pylint: disable=too-few-public
         Filter.apply(self, image_to_filter)
         g = np.ascontiguousarray(image_to_filter, dtype=np.float32)
         mask, fixed, values = backend.lagoons_detection_dev(backend.DeviceRaster.from_host(g))
-        fixed_h = fixed.to_host()
-        sel = np.zeros(g.shape, dtype=bool)
-        sel[1:-1, 1:-1] = g[1:-1, 1:-1] < 0
-        image_to_filter[sel] = fixed_h[sel]                 # CorrectNANValues works in place
+        # CorrectNANValues works in place.  The kernel passes every other cell through bit for
+        # bit, so a float32 raster simply receives the repaired one; any other type only its
+        # repaired cells (its other values need not be float32 numbers).
+        if g is image_to_filter:
+            fixed.ctx.check(fixed.ctx.lib.hdem_memcpy_d2h(fixed.ctx.handle, g.ctypes.data,
+                                                          fixed.ptr, g.nbytes))
+        else:
+            sel = g < 0
+            sel[0] = sel[-1] = False
+            sel[:, 0] = sel[:, -1] = False
+            np.copyto(image_to_filter, fixed.to_host(), where=sel, casting="unsafe")
         self.hsheds_nan_fixed = image_to_filter
-        self.lagoons_values = values.to_host().astype(np.float64)
-        self.mask_lagoons = mask.to_host().astype(np.int64)
+        self.lagoons_values = backend.widened_to_host(values, np.float64)
+        self.mask_lagoons = backend.widened_to_host(mask, np.int64)
         self.results = {"CorrectNANValues": self.hsheds_nan_fixed,
                         "TidyingLagoons": self.lagoons_values,
                         "MaskPositives": self.mask_lagoons}

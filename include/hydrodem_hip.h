@@ -225,7 +225,7 @@ typedef enum hdem_ew_op {
     HDEM_EW_LT = 4,       /* image < operand      LowerThan         :35-50   */
     HDEM_EW_NONZERO = 5   /* image != 0           BooleanToInteger  :113-131 (bool * 1) */
 } hdem_ew_op;
-typedef enum hdem_dtype { HDEM_T_F32 = 0, HDEM_T_F64 = 1, HDEM_T_U8 = 2 } hdem_dtype;
+typedef enum hdem_dtype { HDEM_T_F32 = 0, HDEM_T_F64 = 1, HDEM_T_U8 = 2, HDEM_T_I64 = 3 } hdem_dtype;
 int hdem_elementwise_dev(hdem_ctx *ctx, int op, const void *image, int image_type,
                          const void *operand, int operand_type, double scalar, int64_t n,
                          void *out, int out_type);

@@ -189,7 +189,8 @@ def test_python_constants_match_the_header():
          backend.EW_NONZERO]
     types = dict(re.findall(r"\b(HDEM_T_[A-Z0-9]+)\s*=\s*(\d+)", header))
     assert {np.dtype(np.float32): int(types["HDEM_T_F32"]), np.dtype(np.float64): int(types["HDEM_T_F64"]),
-            np.dtype(np.uint8): int(types["HDEM_T_U8"])} == backend._EW_TYPES
+            np.dtype(np.uint8): int(types["HDEM_T_U8"]),
+            np.dtype(np.int64): int(types["HDEM_T_I64"])} == backend._EW_TYPES
     assert int(enums["HDEM_ERR_WINDOW_EVEN"]) == backend.WINDOW_EVEN
     assert int(enums["HDEM_ERR_WINDOW_HIGH"]) == backend.WINDOW_HIGH
     assert int(enums["HDEM_ERR_NOT_CONVERGED"]) == backend.NOT_CONVERGED
