@@ -823,7 +823,7 @@ def blanks_fourier(q, window_size=55):
     """(found float64 0/1, q * (1 - found)) like BlanksFourier.apply."""
     qd = DeviceRaster.from_host(_host2d(q, np.float32))
     found = blanks_fourier_dev(qd, window_size=window_size)
-    return found.to_host().astype(np.float64), qd.to_host()
+    return widened_to_host(found, np.float64), qd.to_host()
 
 
 def isolated_points(mask, window_size=3):
@@ -831,9 +831,14 @@ def isolated_points(mask, window_size=3):
     return isolated_points_dev(m, window_size).to_host()
 
 
-def expand(mask, window_size=13):
-    m = DeviceRaster.from_host(_host2d(np.asarray(mask) > 0, np.uint8))
-    return expand_dev(m, window_size).to_host()
+def expand(mask, window_size=13, dtype=np.uint8):
+    """ExpandFilter on a host raster (cells > 0 are set); the 0 / 1 result in ``dtype``."""
+    g = np.asarray(mask)
+    if g.dtype in (np.uint8, np.bool_):
+        m = DeviceRaster.from_host(_host2d(g, g.dtype).view(np.uint8))
+    else:
+        m = DeviceRaster.from_host(_host2d(np.greater(g, 0), np.bool_).view(np.uint8))
+    return widened_to_host(expand_dev(m, window_size), dtype)
 
 
 def fft2(x, inverse=False):

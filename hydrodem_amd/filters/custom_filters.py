@@ -325,7 +325,7 @@ class ExpandFilter(Filter):  # pylint: disable=too-few-public-methods
         self.window_size = window_size
 
     def apply(self, image_to_filter):
-        return backend.expand(image_to_filter, self.window_size).astype(np.float64)
+        return backend.expand(image_to_filter, self.window_size, np.float64)
 
 
 class IsolatedPoints(Filter):  # pylint: disable=too-few-public-methods
@@ -546,7 +546,7 @@ class TidyingLagoons(ComposedFilter):  # pylint: disable=too-few-public-methods
         if self._stock():
             img = backend.DeviceRaster.from_host(
                 np.ascontiguousarray(image_to_filter, dtype=np.float32))
-            return backend.tidying_lagoons_dev(img).to_host().astype(np.float64)
+            return backend.widened_to_host(backend.tidying_lagoons_dev(img), np.float64)
         for filter_ in self.filters:
             content = filter_.apply(content)
         return content

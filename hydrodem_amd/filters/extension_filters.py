@@ -121,8 +121,7 @@ class BitwiseXOR(Filter):  # pylint: disable=too-few-public-methods
 
 
 def _mask_raster(image):
-    return backend.DeviceRaster.from_host(
-        np.ascontiguousarray(np.asarray(image) != 0, dtype=np.uint8))
+    return backend.DeviceRaster.from_host(backend.mask_bytes(image))
 
 
 class BinaryErosion(Filter):  # pylint: disable=too-few-public-methods
@@ -135,7 +134,7 @@ class BinaryErosion(Filter):  # pylint: disable=too-few-public-methods
     def apply(self, image_to_filter):
         super().apply(image_to_filter)
         out = backend.binary_erosion_dev(_mask_raster(image_to_filter), self.iterations)
-        return out.to_host().astype(bool)
+        return out.to_host().view(np.bool_)                   # (the kernels write 0 / 1)
 
 
 class BinaryClosing(Filter):  # pylint: disable=too-few-public-methods
@@ -148,7 +147,7 @@ class BinaryClosing(Filter):  # pylint: disable=too-few-public-methods
     def apply(self, image_to_filter):
         super().apply(image_to_filter)
         out = backend.binary_closing_dev(_mask_raster(image_to_filter), self.structure)
-        return out.to_host().astype(bool)
+        return out.to_host().view(np.bool_)
 
 
 class GreyDilation(Filter):  # pylint: disable=too-few-public-methods
@@ -163,5 +162,7 @@ class GreyDilation(Filter):  # pylint: disable=too-few-public-methods
         super().apply(image_to_filter)
         img = backend.DeviceRaster.from_host(np.ascontiguousarray(image_to_filter,
                                                                   dtype=np.float32))
-        return backend.grey_dilation_dev(img, self.size).to_host().astype(
-            image_to_filter.dtype, copy=False)
+        out = backend.grey_dilation_dev(img, self.size)
+        if np.asarray(image_to_filter).dtype == np.float64:
+            return backend.widened_to_host(out, np.float64)
+        return out.to_host().astype(image_to_filter.dtype, copy=False)
