@@ -216,7 +216,7 @@ def cpu_b(z, groves):
              "sample": f"{b}x{b} crop, scipy.ndimage.convolve + np.around, {dt_b:.1f} s"})
 
 
-def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=3):
+def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=8):
     """The other operators of the scope table on the same raster, outside the timed region
     (they are not part of the headline metric): warm call, then ``reps`` timed."""
     import hdem_synth
