@@ -52,3 +52,24 @@ def test_window_limits(built):
         hd.CorrectNANValues(window_size=13).apply(np.zeros((40, 40), dtype=np.float32))
     with pytest.raises(ValueError):
         hd.BlanksFourier(window_size=5).apply(q)
+
+
+@pytest.mark.parametrize("shape,ws", [((300, 1501), 55), ((97, 2050), 21), ((64, 470), 55),
+                                      ((33, 513), 7)])
+def test_blanks_fourier_across_block_seams(built, shape, ws):
+    """Several 458-column blocks side by side and several 32-row segments on top of each
+    other, widths that are no multiple of four: every cell against the NumPy oracle (cells
+    within rounding of the threshold may fall either way; there are none in these cases
+    unless the assert says so)."""
+    from oracle import hdem_oracle_fourier as F
+    rng = np.random.default_rng(shape[1] + ws)
+    q = np.exp(rng.normal(0.0, 1.5, shape)).astype(np.float32)
+    q[rng.random(shape) < 0.002] *= 200.0
+    want, want_q, margin = F.blanks_fourier(q, ws)
+    found, modified = hd.BlanksFourier(window_size=ws).apply(q.copy())
+    diff = found != want
+    borderline = np.abs(margin) <= 1e-6 * np.abs(q)
+    assert not (diff & ~borderline).any(), f"{int((diff & ~borderline).sum())} cells differ"
+    assert found.sum() > 20
+    same = ~diff
+    assert np.array_equal(modified[same], want_q.astype(np.float32)[same])
