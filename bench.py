@@ -55,7 +55,7 @@ VISIT_BYTES_WRITING = 12    # per tile cell: Z in + W in + W out
 VISIT_BYTES_UNCHANGED = 8   # a visit that lowers nothing skips the write-back
 FLOOR_BYTES_PER_CELL = 8    # a whole fill: read Z once, write W once
 FILL_KERNEL = "fill_async_kernel<false, 0>"
-TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "r02_fill_traffic.json")
+TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "r03_fill_traffic.json")
 FILL_SOURCES = ("hydrodem_amd/csrc/hdem_sinkfill.hip", "hydrodem_amd/csrc/hdem_internal.h")
 
 

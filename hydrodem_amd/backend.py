@@ -29,6 +29,7 @@ OK, BAD_ARG, WINDOW_EVEN, WINDOW_HIGH, HIP_ERR, NOT_CONVERGED, NO_DEVICE, OOM = 
 K_D8, K_FILL_INIT, K_FILL_TILE, K_BOXMEAN, K_GROVES, K_CONVOLVE, K_COPY, K_FILL_ROUND = range(8)
 K_BLOCKMAX, K_FFT, K_FOURIER_ROWSUM, K_FOURIER_DETECT, K_FOURIER_MASK, K_FOURIER_POINT = range(8, 14)
 K_LAGOON, K_MAJORITY, K_FILL_COARSE, K_FILL_FLAT, K_ELEMENTWISE = 14, 15, 16, 17, 18
+K_FILL_HUB = 19
 
 # element-wise operators and raster types of hdem_elementwise_dev
 EW_MUL, EW_ADD, EW_RSUB, EW_GT, EW_LT, EW_NONZERO = range(6)
@@ -53,7 +54,7 @@ class FillStats(ctypes.Structure):
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
                 ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64),
                 ("pending", ctypes.c_int64), ("partial_residency", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("flat_unchanged", ctypes.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -72,6 +73,7 @@ SIGNATURES = {
     "hdem_set_fill_coarse_start": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_malloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
     "hdem_free": [_vp, _vp],
+    "hdem_trim": [_vp, _c.POINTER(_c.c_size_t)],
     "hdem_memcpy_h2d": [_vp, _vp, _vp, _c.c_size_t],
     "hdem_memcpy_d2h": [_vp, _vp, _vp, _c.c_size_t],
     "hdem_memcpy_d2d": [_vp, _vp, _vp, _c.c_size_t],
@@ -229,6 +231,13 @@ class Context:
     def set_stream(self, stream_ptr):
         self.check(self.lib.hdem_set_stream(self.handle,
                                             ctypes.c_void_p(stream_ptr or 0)))
+
+    def trim(self):
+        """Hand the context's cached device blocks and scratch buffers back to the
+        device (``hdem_trim``); returns the bytes released."""
+        n = ctypes.c_size_t(0)
+        self.check(self.lib.hdem_trim(self.handle, ctypes.byref(n)))
+        return int(n.value)
 
     # -- timing ----------------------------------------------------------
     def profile(self, on=True):

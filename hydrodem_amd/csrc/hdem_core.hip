@@ -84,6 +84,7 @@ extern "C" int hdem_shutdown(hdem_ctx *ctx)
     hdem_fourier_release(ctx);
     if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
     if (ctx->coarse_buf) (void)hipFree(ctx->coarse_buf);
+    if (ctx->hub_buf) (void)hipFree(ctx->hub_buf);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -100,10 +101,8 @@ void *hdem_arena(hdem_ctx *ctx, size_t bytes)
         ctx->arena = nullptr;
         ctx->arena_bytes = 0;
     }
-    const hipError_t e = hipMalloc(&ctx->arena, bytes);
-    if (e != hipSuccess) {
+    if (hdem_raw_alloc(ctx, bytes, &ctx->arena) != HDEM_OK) {
         ctx->arena = nullptr;
-        hdem_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return nullptr;
     }
     ctx->arena_bytes = bytes;
@@ -142,6 +141,65 @@ void pool_drop(hdem_ctx *ctx, size_t keep_bytes)
 
 }  // namespace
 
+// Every device allocation the library makes for itself (sink-fill workspace, coarse rasters,
+// the arena of the chains, rocFFT work buffers) comes through here: a request the device
+// cannot serve empties this context's block cache and is tried once more, so memory parked
+// by hdem_free never stands between the library and an allocation it needs.
+int hdem_raw_alloc(hdem_ctx *ctx, size_t bytes, void **dptr)
+{
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> guard(ctx->pool_lock);
+            pool_drop(ctx, 0);
+        }
+        e = hipMalloc(dptr, bytes ? bytes : 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *dptr = nullptr;
+        hdem_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? HDEM_ERR_OOM : HDEM_ERR_HIP;
+    }
+    return HDEM_OK;
+}
+
+extern "C" int hdem_trim(hdem_ctx *ctx, size_t *released)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> guard(ctx->pool_lock);
+        bytes = ctx->pool_bytes;
+        pool_drop(ctx, 0);
+    }
+    // the scratch the context keeps between calls goes too; it grows back on demand
+    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) {
+        bytes += ctx->arena_bytes;
+        (void)hipFree(ctx->arena);
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+    }
+    if (ctx->coarse_buf) {
+        bytes += ctx->coarse_bytes;
+        (void)hipFree(ctx->coarse_buf);
+        ctx->coarse_buf = nullptr;
+        ctx->coarse_bytes = 0;
+    }
+    if (ctx->hub_buf) {
+        bytes += ctx->hub_bytes;
+        (void)hipFree(ctx->hub_buf);
+        ctx->hub_buf = nullptr;
+        ctx->hub_bytes = 0;
+    }
+    if (released) *released = bytes;
+    return HDEM_OK;
+}
+
 extern "C" int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr)
 {
     HDEM_REQUIRE(ctx && dptr, HDEM_ERR_BAD_ARG, "null argument");
@@ -164,7 +222,7 @@ extern "C" int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr)
         // whatever still runs on the block was enqueued before `ready`
         HDEM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, b.ready, 0));
         ctx->pool_events.push_back(b.ready);
-        ctx->pool_live[b.p] = b.bytes;
+        ctx->pool_live[b.p] = {b.bytes, ctx->stream};
         *dptr = b.p;
         return HDEM_OK;
     }
@@ -179,7 +237,7 @@ extern "C" int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr)
         hdem_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? HDEM_ERR_OOM : HDEM_ERR_HIP;
     }
-    ctx->pool_live[*dptr] = bytes;
+    ctx->pool_live[*dptr] = {bytes, ctx->stream};
     return HDEM_OK;
 }
 
@@ -190,8 +248,14 @@ extern "C" int hdem_free(hdem_ctx *ctx, void *dptr)
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> guard(ctx->pool_lock);
     const auto it = ctx->pool_live.find(dptr);
-    const size_t bytes = it == ctx->pool_live.end() ? 0 : it->second;
+    const size_t bytes = it == ctx->pool_live.end() ? 0 : it->second.bytes;
+    // The cache orders a block's next use behind an event on the context's stream.  That
+    // covers everything this context enqueued on it -- provided the stream is still the one
+    // the block was handed out under.  If hdem_set_stream has changed it since, work on the
+    // old stream may still use the block: wait for the whole device first, as hipFree would.
+    const bool stream_changed = it != ctx->pool_live.end() && it->second.stream != ctx->stream;
     if (it != ctx->pool_live.end()) ctx->pool_live.erase(it);
+    if (stream_changed) HDEM_HIP_CHECK(hipDeviceSynchronize());
     if (!ctx->pool_cap) {
         // a quarter of the device, at most 64 GiB (HDEM_POOL_MIB: another figure, 0 = keep nothing)
         size_t free_b = 0, total_b = 0;

@@ -187,7 +187,8 @@ int ensure_plans(hdem_ctx *ctx, int H, int W)
         if (w1 > s->work_bytes) s->work_bytes = w1;
         if (w1) s->split_needs_work = true;          // (lengths that take Bluestein's route)
     }
-    if (s->work_bytes) HDEM_HIP_CHECK(hipMalloc(&s->work, s->work_bytes));
+    if (s->work_bytes)
+        if (int rc = hdem_raw_alloc(ctx, s->work_bytes, &s->work)) return rc;
     HDEM_REQUIRE(g_fft.info_create(&s->info) == 0, HDEM_ERR_HIP, "rocfft info_create failed");
     if (s->work_bytes)
         HDEM_REQUIRE(g_fft.info_set_work_buffer(s->info, s->work, s->work_bytes) == 0,
@@ -898,7 +899,8 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
     const size_t bytes = n * sizeof(float2) + 2 * qn8 * sizeof(float) + 4 * qn8 + occ_bytes +
                          (SUM_BLOCKS + 1) * sizeof(double);
     hdem_fourier_state *fs = ctx->fourier;
-    if (!fs->scratch) HDEM_HIP_CHECK(hipMalloc(&fs->scratch, bytes));
+    if (!fs->scratch)
+        if (int rc = hdem_raw_alloc(ctx, bytes, &fs->scratch)) return rc;
     char *base = (char *)fs->scratch;
     struct view { void *p; } F{base}, q{base + n * sizeof(float2)},
         q1{(char *)q.p + qn8 * sizeof(float)}, det{(char *)q1.p + qn8 * sizeof(float)},
@@ -965,7 +967,7 @@ extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, in
         float2 *G = !fs->split_needs_work && fs->work_bytes >= n * sizeof(float2) ? (float2 *)fs->work
                                                                                   : (float2 *)fs->tr;
         if (!G) {
-            HDEM_HIP_CHECK(hipMalloc(&fs->tr, n * sizeof(float2)));
+            if (int rc = hdem_raw_alloc(ctx, n * sizeof(float2), (void **)&fs->tr)) return rc;
             G = (float2 *)fs->tr;
         }
         HDEM_REQUIRE(g_fft.info_set_stream(fs->info, st) == 0, HDEM_ERR_HIP, "rocfft set_stream failed");

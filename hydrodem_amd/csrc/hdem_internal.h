@@ -49,6 +49,11 @@ struct hdem_cached_block {
     hipEvent_t ready;
 };
 
+struct hdem_live_block {
+    size_t bytes;
+    hipStream_t stream;               // the context's stream when the block was handed out
+};
+
 struct hdem_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -76,6 +81,8 @@ struct hdem_ctx {
     uint8_t *fill_d8 = nullptr;        // D8 raster the certifying pass of the next fill writes
     bool fill_d8_done = false;         // ... and whether it did
     size_t coarse_bytes = 0;
+    void *hub_buf = nullptr;           // hub start of the sink fill: rim lines, hub raster
+    size_t hub_bytes = 0;
     void *arena = nullptr;             // scratch of the multi-kernel chains, grown on demand
     size_t arena_bytes = 0;
     hdem_fourier_state *fourier = nullptr;
@@ -86,7 +93,7 @@ struct hdem_ctx {
     // allocates its intermediates at every call, and hipMalloc + hipFree of a 1 GiB raster
     // cost 0.3 ms + a device-wide wait
     std::mutex pool_lock;
-    std::unordered_map<void *, size_t> pool_live;      // blocks handed out: their size
+    std::unordered_map<void *, hdem_live_block> pool_live;   // blocks handed out
     std::vector<hdem_cached_block> pool_free;          // oldest first
     std::vector<hipEvent_t> pool_events;               // spare `ready` events
     size_t pool_bytes = 0, pool_cap = 0;
@@ -106,6 +113,9 @@ void hdem_fourier_release(hdem_ctx *ctx);
 // A device buffer of at least `bytes` that stays with the context (one user at a time:
 // the chains carve it up themselves).  nullptr + error set on failure.
 void *hdem_arena(hdem_ctx *ctx, size_t bytes);
+// hipMalloc for the library's own long-lived buffers: retried once after emptying the
+// context's block cache.  HDEM_OK / HDEM_ERR_OOM / HDEM_ERR_HIP, error text set.
+int hdem_raw_alloc(hdem_ctx *ctx, size_t bytes, void **dptr);
 // hdem_stencil.hip: streaming certification of a filled surface (+ its D8 codes)
 int hdem_certify_d8_launch(hdem_ctx *ctx, const float *z, const float *w, int H, int W, float eps,
                            uint8_t *d8, int *flag);

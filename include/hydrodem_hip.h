@@ -60,9 +60,19 @@ int hdem_synchronize(hdem_ctx *ctx);
  * again for a request of that size or up to an eighth less; the new owner's stream waits
  * for whatever the context's stream held at the time of the free -- no host wait, no
  * hipMalloc / hipFree in a chain of operators that allocates at every call.  A block is
- * handed back on the context it came from; hdem_shutdown returns everything. */
+ * handed back on the context it came from; hdem_shutdown returns everything.
+ * Contract (single stream): when hdem_free is called, every use of the block must have been
+ * enqueued on THIS context's stream (or be complete).  A block that another context, or a
+ * stream of the caller's own, still works on must be synchronised by the caller before it is
+ * freed (hdem_synchronize on that context); a context whose stream was changed with
+ * hdem_set_stream since the block was handed out waits for the whole device in hdem_free.
+ * hdem_trim gives the cached blocks (and the scratch buffers the context keeps between calls)
+ * back to the device -- for a process that shares the GPU with another allocator (a second
+ * context, torch); every allocation the library makes for itself does the same before it
+ * reports HDEM_ERR_OOM.  *released (may be NULL): bytes returned. */
 int hdem_malloc(hdem_ctx *ctx, size_t bytes, void **dptr);
 int hdem_free(hdem_ctx *ctx, void *dptr);
+int hdem_trim(hdem_ctx *ctx, size_t *released);
 int hdem_memcpy_h2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2h(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
@@ -96,7 +106,8 @@ typedef enum hdem_kernel_id {
     HDEM_K_FILL_COARSE = 16,    /* sink fill: asynchronous launch of the coarse pre-solve */
     HDEM_K_FILL_FLAT = 17,      /* sink fill: interiors of the tiles that ended flat      */
     HDEM_K_ELEMENTWISE = 18,    /* element-wise operators on device rasters               */
-    HDEM_K_COUNT = 19
+    HDEM_K_FILL_HUB = 19,       /* sink fill: hub start (in-tile path costs + hub raster)  */
+    HDEM_K_COUNT = 20
 } hdem_kernel_id;
 
 typedef struct hdem_kernel_stat {
@@ -135,7 +146,8 @@ typedef struct hdem_fill_stats {
     int32_t partial_residency;/* 1: some workgroups of the asynchronous launch were not
                                  resident within 200 us (the GPU is shared); the others
                                  started without them and took their tiles       */
-    int32_t reserved;
+    int32_t flat_unchanged;   /* of visits_flat: those that found nothing to lower (they are
+                                 part of visits_unchanged as well)               */
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */

@@ -5,11 +5,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hydrodem_amd import backend as B
 import hdem_synth
-n = 16384
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = B.context()
 zd = B.DeviceRaster.from_host(hdem_synth.synth_dem(n, n)); wd = B.DeviceRaster.empty((n, n), np.float32)
 dd = B.DeviceRaster.empty((n, n), np.uint8)
 for rep in range(6):
     ctx.profile(True); ctx.profile_reset()
-    t = time.time(); B.sinkfill_d8_dev(zd, out=wd, codes=dd); ctx.synchronize(); dt = time.time() - t
-    print(f"step {dt*1e3:.2f} ms: init {ctx.profile_get(B.K_FILL_INIT)['ms']:.3f} tile {ctx.profile_get(B.K_FILL_TILE)['ms']:.3f} coarse {ctx.profile_get(B.K_FILL_COARSE)['ms']:.3f} blockmax {ctx.profile_get(B.K_BLOCKMAX)['ms']:.3f}")
+    t = time.time(); _, _, st = B.sinkfill_d8_dev(zd, out=wd, codes=dd); ctx.synchronize(); dt = time.time() - t
+    g = lambda k: ctx.profile_get(k)['ms']
+    print(f"step {dt*1e3:.2f} ms: hub {g(B.K_FILL_HUB):.3f} blockmax {g(B.K_BLOCKMAX):.3f} coarse {g(B.K_FILL_COARSE):.3f} "
+          f"init/apply {g(B.K_FILL_INIT):.3f} tile {g(B.K_FILL_TILE):.3f} flat {g(B.K_FILL_FLAT):.3f} certify {g(B.K_FILL_ROUND):.3f}; visits {st['tile_visits']} "
+          f"({st['tile_visits']/st['tiles']:.2f}/tile) unchanged {st['visits_unchanged']} flat {st['visits_flat']}", flush=True)
