@@ -2,7 +2,7 @@
 """
 bench.py -- the hot path's headline metric on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--config 4|5]
 
 Metric (BASELINE.json): Mcells/s of SinkFill (to convergence) + D8FlowDirection
 on a 16384^2 float32 DEM, inputs resident in HBM when the timed region starts,
@@ -10,7 +10,10 @@ outputs left in HBM.  One "step" = one full sink fill + D8 of the raster.
 
 N > 1: the raster is N*S rows x S columns, row-block partitioned, S rows per rank --
 weak scaling -- with seam exchanges between local solves (hydrodem_amd/partition.py),
-one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
+one process per GPU over RCCL.  --config 4 / --config 5 run BASELINE's named multi-GPU
+configurations instead: the 32768^2 raster on 4 GPUs (8192 x 32768 per rank) and the
+65536^2 mosaic on 8 (8192 x 65536 per rank); with another --gpus N the same raster is cut
+into N row blocks (then it is a strong-scaling point and the line says so).  Under torch.distributed.run (RANK / WORLD_SIZE in the
 environment) this process is one rank; started plainly (`python bench.py --gpus N`) it
 starts its N ranks itself, as fresh child processes, before anything touches a GPU.
 HDEM_REHEARSE=1 puts every rank on cuda:0 over gloo: the N > 1 code path on a one-GPU
@@ -65,6 +68,9 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--size", type=int, default=16384)
+    p.add_argument("--config", type=int, default=0, choices=(0, 4, 5),
+                   help="BASELINE configs[3] / configs[4]: 32768^2 on 4 GPUs, 65536^2 on 8 "
+                        "(sets the raster; --gpus defaults to the configuration's)")
     p.add_argument("--cpu-sample", type=int, default=1024,
                    help="edge of the crop the NumPy Jacobi oracle is timed on (0 = no CPU lines)")
     p.add_argument("--no-filters", action="store_true",
@@ -242,6 +248,10 @@ def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=8):
         B.groves_dev(zd, mask, iterations=3, out=scratch, scratch=pong)
         B.sinkfill_d8_dev(scratch, out=filled, codes=codes)
     res["full_chain_groves_fill_d8"] = line(timed(ctx, chain, reps))
+    # the chain's end-to-end floor: groves x3 27 B/cell, fill 8 (Z in, W out), D8 codes 1
+    res["full_chain_groves_fill_d8"].update(
+        floor_bytes_per_cell=36,
+        useful_frac=36 * S * S / res["full_chain_groves_fill_d8"]["ms"] / 1e6 / HBM_PEAK_GBS)
     res["d8_alone"] = line(timed(ctx, lambda: B.d8_dev(filled, out=codes), reps), 5)
     for r in (mask, pong, filled, codes):
         r.free()
@@ -268,7 +278,12 @@ def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=8):
     del z_host, groves_host
     ctx.profile(True)
     ctx.profile_reset()
-    res["fourier_destripe"] = line(timed(ctx, lambda: B.fourier_destripe_dev(zd, out=scratch), reps))
+    # algorithmic bytes per raster cell, stage by stage: reference level 8; real
+    # forward transform 4 in + 8 out, its Hermitian completion 8; two quadrant magnitudes
+    # (a quarter of the cells each) 12 / 2; hollow mean 9 per quadrant cell x 2 passes x 2
+    # quadrants / 4; masks ~1; inverse: two row passes 16 + 16, transpose 16, transpose + abs 12
+    res["fourier_destripe"] = line(timed(ctx, lambda: B.fourier_destripe_dev(zd, out=scratch), reps),
+                                   8 + 12 + 8 + 6 + 9 + 1 + 60)
     n_calls = reps + 1
     for name, kid in (("rocfft_c2c", B.K_FFT), ("detect", B.K_FOURIER_DETECT),
                       ("mask", B.K_FOURIER_MASK), ("pointwise", B.K_FOURIER_POINT)):
@@ -296,7 +311,8 @@ def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=8):
     def lagoons():
         ctx.check(ctx.lib.hdem_lagoons_detection_f32_dev(ctx.handle, hd_.ptr, S, S, l_fixed.ptr,
                                                          scratch.ptr, l_mask.ptr))
-    res["lagoons_detection"] = line(timed(ctx, lagoons, reps))
+    # void repair 8 + majority 8 + fused tidy 9 (with the positive mask) B per cell
+    res["lagoons_detection"] = line(timed(ctx, lagoons, reps), 25)
     res["lagoons_detection"]["majority_ms"] = ctx.profile_get(B.K_MAJORITY)["ms"] / n_calls
     res["lagoons_detection"]["other_kernels_ms"] = ctx.profile_get(B.K_LAGOON)["ms"] / n_calls
     ctx.profile(False)
@@ -306,27 +322,71 @@ def filter_paths(B, ctx, zd, scratch, S, copy_gbs, with_cpu, reps=8):
 
 
 def config2(B, ctx, steps=10):
-    """BASELINE configs[1]: 4096 x 4096, sink fill + D8 on one GPU (below the size from which
-    the fill starts from a coarse solve)."""
+    """BASELINE configs[1]: 4096 x 4096, sink fill + D8 on one GPU."""
     import hdem_synth
     s = 4096
-    zd = B.DeviceRaster.from_host(hdem_synth.synth_dem(s, s), ctx=ctx)
+    return fill_line(B, ctx, hdem_synth.synth_dem(s, s),
+                     f"BASELINE configs[1]: {s}x{s} float32 synthetic DEM, SinkFill eps=0 + D8", steps)
+
+
+def fill_line(B, ctx, z, workload, steps=10):
+    """Fill + D8 of one raster, resident: time, visits, and the fine launch against the roof
+    the way the headline line states it."""
+    zd = B.DeviceRaster.from_host(z, ctx=ctx)
     wd = B.DeviceRaster.empty(zd.shape, np.float32, ctx)
     dd = B.DeviceRaster.empty(zd.shape, np.uint8, ctx)
-    info = {}
-    ms = timed(ctx, lambda: info.update(B.sinkfill_d8_dev(zd, out=wd, codes=dd)[2]), steps)
+    stats = []
+    call = lambda: stats.append(B.sinkfill_d8_dev(zd, out=wd, codes=dd)[2])
+    call()
+    ctx.synchronize()
+    del stats[:]
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    ctx.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    kt = ctx.profile_get(B.K_FILL_TILE)
+    ctx.profile(False)
     for r in (zd, wd, dd):
         r.free()
-    return {"workload": f"{s}x{s} float32 synthetic DEM, SinkFill eps=0 + D8", "steps": steps,
-            "ms_per_step": ms, "Mcells_per_s": s * s / ms / 1e3,
+    cells = z.size
+    info = stats[-1]
+    unchanged = sum(s_["visits_unchanged"] - s_.get("flat_unchanged", 0) for s_ in stats) * 62 * 62
+    visit_bytes = VISIT_BYTES_WRITING * kt["units"] - \
+        (VISIT_BYTES_WRITING - VISIT_BYTES_UNCHANGED) * min(unchanged, kt["units"])
+    gbs = visit_bytes / max(kt["ms"], 1e-9) / 1e6
+    return {"workload": workload, "steps": steps,
+            "ms_per_step": ms, "Mcells_per_s": cells / ms / 1e3,
             "tile_visits_per_step": info.get("tile_visits"), "tiles": info.get("tiles"),
-            "useful_frac": FLOOR_BYTES_PER_CELL * s * s / ms / 1e6 / HBM_PEAK_GBS}
+            "visits_per_tile": (info.get("tile_visits") or 0) / max(info.get("tiles") or 1, 1),
+            "fill_async_ms_per_step": kt["ms"] / steps,
+            "algorithmic_bytes_per_cell_visit": VISIT_BYTES_WRITING,
+            "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "useful_frac": FLOOR_BYTES_PER_CELL * cells / ms / 1e6 / HBM_PEAK_GBS}
+
+
+def config1(B, ctx):
+    """BASELINE configs[0]'s raster on the GPU path: the reference's own 519 x 508 study-area
+    DEM (cguerrero/resources/images/final_dem.tif, committed as tests/golden/ref_rasters.npz
+    by tests/golden/make_golden.py), integer metres with ties everywhere."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_rasters.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.ascontiguousarray(np.load(path)["final_dem"], dtype=np.float32)
+    return fill_line(B, ctx, z, "BASELINE configs[0]'s raster: the reference's 519x508 final_dem.tif, "
+                                "SinkFill eps=0 + D8 (latency-bound: 81 tiles)", 20)
 
 
 # --------------------------------------------------------------------------
 def main():
     a = parse()
     S, N = a.size, a.gpus
+    if a.config:
+        if N == 1 and "WORLD_SIZE" not in os.environ and "--gpus" not in " ".join(sys.argv):
+            N = a.gpus = {4: 4, 5: 8}[a.config]
+            sys.argv += ["--gpus", str(N)]
     if N > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(N)
         return
@@ -340,6 +400,7 @@ def main():
     from hydrodem_amd import backend as B
 
     step_stats = []                 # per timed step: visits / unchanged / ...
+    H, Wd = S, S
     if N == 1:
         ctx = B.context(0)
         z = hdem_synth.synth_dem(S, S)
@@ -366,10 +427,13 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearse else "nccl")
-        H = N * S
+        if a.config:
+            H = Wd = {4: 32768, 5: 65536}[a.config]     # the named raster, cut into N blocks
+        else:
+            H, Wd = N * S, S                            # weak scaling: S rows per rank
         ghost = P.ghost_rows(world, H)                  # one tile row of overlap per seam
         g0, g1, _, _ = P.local_range(rank, world, H, ghost)
-        z = hdem_synth.synth_dem(H, S, row0=g0, rows=g1 - g0)
+        z = hdem_synth.synth_dem(H, Wd, row0=g0, rows=g1 - g0)
         dev = torch.device("cuda", local_rank)
         zt = torch.from_numpy(z).to(dev)
         wt = torch.empty_like(zt)
@@ -412,12 +476,13 @@ def main():
     kb = ctx.profile_get(B.K_BLOCKMAX)
     kr = ctx.profile_get(B.K_FILL_ROUND)
     ki = ctx.profile_get(B.K_FILL_INIT)
+    kh = ctx.profile_get(B.K_FILL_HUB)
     ctx.profile(False)
     last = step_stats[-1]
     per_rank = None
     if N > 1:
         # every rank's share of the step, gathered after the timed region
-        mine = torch.tensor([kt["ms"], kc["ms"] + kb["ms"], kr["ms"], ki["ms"],
+        mine = torch.tensor([kt["ms"], kc["ms"] + kb["ms"] + kh["ms"], kr["ms"], ki["ms"],
                              float(sum(s["tile_visits"] for s in step_stats)),
                              float(sum(s["visits_unchanged"] for s in step_stats)),
                              float(last["tiles"] or 0), float(last["exchanges"]),
@@ -448,12 +513,14 @@ def main():
 
     if rank == 0:
         copy_gbs = B.copy_rate(ctx)
-        cells_total = N * S * S
+        cells_total = H * Wd
         ms_per_step = elapsed / a.steps * 1e3
-        # rank 0's fill launches: cells of all tile visits (profile units), of which the
-        # unchanged ones skipped the write-back
+        # rank 0's fill launches: cells of all window visits (profile units; visits of flat
+        # tiles read ~500 cells and are not in them), of which the unchanged ones skipped the
+        # write-back
         ft2 = 62 * 62
-        unchanged_cells = sum(s["visits_unchanged"] for s in step_stats) * ft2
+        unchanged_cells = sum(s["visits_unchanged"] - s.get("flat_unchanged", 0)
+                              for s in step_stats) * ft2
         visit_bytes = VISIT_BYTES_WRITING * kt["units"] - \
             (VISIT_BYTES_WRITING - VISIT_BYTES_UNCHANGED) * min(unchanged_cells, kt["units"])
         fill_gbs = visit_bytes / max(kt["ms"], 1e-9) / 1e6
@@ -466,8 +533,8 @@ def main():
             "copy_rate_measured": copy_gbs,
             "useful_frac": useful_gbs / HBM_PEAK_GBS,
             "useful_frac_of_copy": useful_gbs / copy_gbs,
-            "end_to_end_bytes_over_floor": (visit_bytes / a.steps + 17.0 * S * S)
-                                           / (FLOOR_BYTES_PER_CELL * S * S),
+            "end_to_end_bytes_over_floor": (visit_bytes / a.steps + 17.0 * cells_total / N)
+                                           / (FLOOR_BYTES_PER_CELL * cells_total / N),
             "traffic": traffic,
             "counter_to_algorithmic": traffic / (visit_bytes / launches) if traffic else None,
             "launches": kt["launches"], "ms_total": kt["ms"],
@@ -476,12 +543,15 @@ def main():
             "note": "rank 0.  achieved/frac: algorithmic bytes of the tile visits (12 B per cell "
                     "of a writing visit, 8 B of an unchanged one) over the kernel's HIP-event "
                     "time; useful_frac: 8 B per raster cell over the whole step.  "
-                    "end_to_end_bytes_over_floor adds init (8 B/cell) and the certifying pass "
-                    "(9 B/cell)"})
+                    "end_to_end_bytes_over_floor adds the start values (hub start: Z in, d out, "
+                    "8 B/cell) and the certifying pass (9 B/cell)"})
         roofline.update(traffic_meta)
         certify_gbs = 9 * kr["units"] / max(kr["ms"], 1e-9) / 1e6
         init_gbs = 8 * ki["units"] / max(ki["ms"], 1e-9) / 1e6
-        size_name = f"{S}^2" if N == 1 else f"{N * S}x{S}"
+        size_name = f"{S}^2" if N == 1 else f"{H}x{Wd}"
+        hub_gbs = 8 * kh["units"] / max(kh["ms"], 1e-9) / 1e6
+        named = {4: "BASELINE configs[3]: 32768x32768 DEM, row-block decomposed, 4 GPUs",
+                 5: "BASELINE configs[4]: 65536x65536 mosaic, 8 GPUs"}.get(a.config)
         out = {
             "metric": f"Mcells/s sink-fill+D8 on {size_name} float32 DEM",
             "value": cells_total * a.steps / elapsed / 1e6,
@@ -489,15 +559,16 @@ def main():
             "n_gpus": N, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.config and N != {4: 4, 5: 8}[a.config] else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{N * S}x{S} float32 synthetic DEM (SURVEY 8d 'rough': "
+            "config": {"workload": (named + ": " if named else "") +
+                                   f"{H}x{Wd} float32 synthetic DEM (SURVEY 8d 'rough': "
                                    f"plane + 4 sinusoids + 0.5 m noise + 0.1% pits), "
                                    f"SinkFill eps=0 to exact convergence + D8; "
-                                   f"{S} rows per GPU, row-block partition",
-                       "rows_per_gpu": S, "cols": S,
+                                   f"{H // N} rows per GPU, row-block partition",
+                       "rows_per_gpu": H // N, "cols": Wd,
                        "tile_visits_per_step": last.get("tile_visits"),
                        "tiles": last.get("tiles"),
                        "visits_per_tile": (last.get("tile_visits") or 0) / max(last.get("tiles") or 1, 1),
@@ -519,18 +590,26 @@ def main():
                             ms_per_step=ki["ms"] / a.steps,
                             note="start values of the fine raster (and of the coarse one: two "
                                  "launches per step)"),
-                        "coarse_pre_solve": {
+                        "hub_dist_kernel": dict(
+                            roofs(hub_gbs, copy_gbs), algorithmic_bytes_per_cell=8,
+                            ms_per_step=kh["ms"] / a.steps,
+                            note="hub start: per tile the minimax path cost of every cell to "
+                                 "the tile's hub (Z in, d out) + the crossings between hubs; "
+                                 "two rounds of directional scans per tile, instruction-bound"),
+                        "start_raster_solve": {
                             "blockmax_avg_launch_ms": kb["ms"] / max(kb["launches"], 1),
                             "fill_async_kernel<false, 1>_avg_launch_ms":
                                 kc["ms"] / max(kc["launches"], 1),
-                            "note": "fill of the 16x16 block maxima (1/256 of the cells): start "
-                                    "values of the fine solve; latency-bound"}},
+                            "note": "fill of the hub raster (one node per 62x62 tile and the "
+                                    "crossings between them, 1/930 of the cells; N > 1: of the "
+                                    "16x16 block maxima): latency-bound"}},
         }
         if per_rank:
             out["per_rank"] = per_rank
         if N == 1 and not a.no_filters:
             out["filters"] = filter_paths(B, ctx, zd, wd, S, copy_gbs, bool(a.cpu_sample))
             out["config2"] = config2(B, ctx)
+            out["config1_raster"] = config1(B, ctx)
         if a.cpu_sample and N == 1:
             out["cpu_baseline"] = cpu_baseline(z, a.cpu_sample)
         print(json.dumps(out), flush=True)

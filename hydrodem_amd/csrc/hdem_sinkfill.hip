@@ -62,6 +62,9 @@ constexpr int KEY_NONE = 0x7fffffff;   // "no key": above every float_key()
 constexpr int SEED_KEYS = 1 << 20;     // queue keys below this: seeds (flood order)
 constexpr int AUX_SC1 = 16;            // buffer-instruction cache policy: sc1 (agent scope)
 constexpr int COARSE_SHIFT = 4;    // own coarse start: 16 x 16 blocks ...
+constexpr int HUB_EDGE = 4 * WN;        // hub start, floats per tile: N row, S row (lane = column),
+                                        // W column, E column (lane = row) of d on the tile's rim
+constexpr float HUB_BIG = 3.0e38f;      // a wall of the hub raster (finite: not nodata)
 constexpr int HUB_MIN_TILES = 256;     // hub start (below) from this many tiles on (~1000^2 cells)
 constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on (below, the
                                    // two extra launches cost what they save)
@@ -96,6 +99,7 @@ struct fill_ws {
     unsigned long long *stats;   // [G][STAT_WORDS], written only by the owner
     int *flat;          // [ntiles] float bits: level of a tile whose interior is one level
     int *zmax;          // [ntiles] float bits: highest terrain of that interior (FLAT_NONE: -)
+    int *applied;       // [ntiles] hub start: 1 once the tile has had its first visit
     int ntiles, tiles_x, tiles_y, max_rounds, G, S;
 };
 
@@ -264,6 +268,14 @@ __device__ __forceinline__ int float_key(float f)
 #define PROF_MARK(k) do { } while (0)
 #endif
 
+// Hub start: a tile holds d (cost to its hub) until its first visit makes max(d, level of the
+// hub) of it.  lv[3 * (dy + 1) + dx + 1]: that level for the tile at (ty + dy, tx + dx) while
+// it has not had its first visit, -inf once it has (or when there is no such tile).
+struct hub_bounds {
+    float lv[9];
+    bool mine;         // this tile's own first visit: write the tile back whatever happens
+};
+
 struct visit_result {
 #ifdef HDEM_VISIT_PROF
     long long ticks[6];   // load, first check, zt transpose, iterations, store, wake tests
@@ -286,7 +298,8 @@ template <bool HAS_EPS, bool COHERENT>
 __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg, float *wg,
                                                    int H, int W, float eps, int ty, int tx,
                                                    float *T, uint8_t *d8 = nullptr,
-                                                   float flat_level = HDEM_INF)
+                                                   float flat_level = HDEM_INF,
+                                                   const hub_bounds *hb = nullptr)
 {
     const int lane = threadIdx.x;
     const int y0 = ty * FT, x0 = tx * FT;              // window origin (= halo row/col)
@@ -338,10 +351,26 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     // hand-off: 6.2 against 5.9 ms.)
     unsigned long long free_n = ~0ull, free_s = ~0ull;
     unsigned fw_lo = 0, fw_hi = 0, fe_lo = 0, fe_hi = 0;
+    // (hub start) cells of tiles that have not had their first visit still hold d: raise them
+    // to their tile's start bound -- per lane the bound of the tile above / beside / below
+    float hub_t = -HDEM_INF, hub_m = -HDEM_INF, hub_b = -HDEM_INF;
+    if (COHERENT && hb) {
+        const int k = lane == 0 ? 0 : (lane == WN - 1 ? 2 : 1);
+        hub_t = k == 0 ? hb->lv[0] : (k == 1 ? hb->lv[1] : hb->lv[2]);
+        hub_m = k == 0 ? hb->lv[3] : (k == 1 ? hb->lv[4] : hb->lv[5]);
+        hub_b = k == 0 ? hb->lv[6] : (k == 1 ? hb->lv[7] : hb->lv[8]);
+    }
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
         const int y = y0 + r;
         float wc = fminf(w[r], HDEM_INF), zc = fminf(z[r], HDEM_INF);
+        if (COHERENT && hb) {
+            // (tile interiors only: on the raster's last tiles the window also holds the
+            // raster ring, which is the boundary condition, not a start value)
+            float bound = r == 0 ? hub_t : (r == WN - 1 ? hub_b : hub_m);
+            if (partial && (x >= W - 1 || y >= H - 1)) bound = -HDEM_INF;
+            wc = fmaxf(wc, bound);
+        }
         if (partial && (lane_out || y >= H)) { wc = HDEM_INF; zc = HDEM_INF; }
         if (COHERENT) {
             // rows 0 / 63: the halo rows, one bit per lane; every row: its two halo-column
@@ -384,12 +413,13 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     V.all |= V.first | V.last;
     bool more = V.all != 0;
     out.changed = more;
+    const bool force_store = COHERENT && hb && hb->mine;
     // lanes whose cell of row 1 / row 62 / column 1 / column 62 moved during the visit
     // (columns: lane = row) -- what the wake tests below are gated on
     const unsigned long long b1 = 1ull << 1, bl = 1ull << FT;
     unsigned long long mv_r1 = V.first, mv_r62 = V.last, mv_c1 = V.all & b1, mv_c62 = V.all & bl;
     PROF_MARK(1);
-    if (more) {
+    if (more || force_store) {
         float zt[WN];
 #pragma unroll
         for (int r = 0; r < WN; ++r) zt[r] = z[r];
@@ -831,7 +861,8 @@ struct flat_result {
 };
 
 __device__ __attribute__((noinline)) flat_result flat_visit(float *wg, int H, int W, int ty, int tx,
-                                                            float L, float zmax)
+                                                            float L, float zmax,
+                                                            const hub_bounds *hb)
 {
     const int lane = threadIdx.x;
     const int y0 = ty * FT, x0 = tx * FT;
@@ -845,8 +876,16 @@ __device__ __attribute__((noinline)) flat_result flat_visit(float *wg, int H, in
                          wrsrc, off, 0, AUX_SC1)), HDEM_INF);          // nodata: a wall
     };
     // (only tiles whose window lies inside the raster are ever flat)
-    const float top = ld(at(0, lane)), bottom = ld(at(WN - 1, lane));
-    const float left = ld(at(lane, 0)), right = ld(at(lane, WN - 1));       // lane = row
+    float top = ld(at(0, lane)), bottom = ld(at(WN - 1, lane));
+    float left = ld(at(lane, 0)), right = ld(at(lane, WN - 1));             // lane = row
+    if (hb) {
+        // (hub start) halo cells of tiles that still hold d: raised to their start bound
+        const int k = lane == 0 ? 0 : (lane == WN - 1 ? 2 : 1);
+        top = fmaxf(top, k == 0 ? hb->lv[0] : (k == 1 ? hb->lv[1] : hb->lv[2]));
+        bottom = fmaxf(bottom, k == 0 ? hb->lv[6] : (k == 1 ? hb->lv[7] : hb->lv[8]));
+        left = fmaxf(left, k == 0 ? hb->lv[0] : (k == 1 ? hb->lv[3] : hb->lv[6]));
+        right = fmaxf(right, k == 0 ? hb->lv[2] : (k == 1 ? hb->lv[5] : hb->lv[8]));
+    }
     const float low = wave_min(fminf(fminf(top, bottom), fminf(left, right)));
     flat_result out = {1, false, 0u, L};
     if (low >= L) return out;                       // nothing new
@@ -879,14 +918,32 @@ __device__ __attribute__((noinline)) flat_result flat_visit(float *wg, int H, in
 }
 
 // The interiors of the tiles that ended the launch flat (their edge lines are in place).
-__global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int W, int tiles_x, int ntiles,
-                                                        const int *__restrict__ flat)
+// Hub start: a tile the launch never got to (a launch cut short by its budget) still holds d;
+// it gets its start bound here, so that whatever runs next finds upper bounds everywhere.
+__global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int H, int W, int tiles_x,
+                                                        int ntiles, const int *__restrict__ flat,
+                                                        const float *__restrict__ hub_lev,
+                                                        const int *__restrict__ applied)
 {
     const int t = blockIdx.x;
-    if (t >= ntiles || flat[t] == FLAT_NONE) return;
+    if (t >= ntiles) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const float level = __builtin_bit_cast(float, flat[t]);
     const int lane = threadIdx.x;
+    if (hub_lev && !applied[t]) {
+        float l = hub_lev[(size_t)(2 * ty + 1) * (2 * tiles_x + 1) + 2 * tx + 1];
+        if (l >= HUB_BIG) l = HDEM_INF;
+        const int x = tx * FT + lane;
+        if (l == l && lane >= 1 && lane <= FT && x <= W - 2) {
+            float *p = wg + (size_t)(ty * FT + 1) * W + x;
+            for (int r = 1; r <= FT && ty * FT + r <= H - 2; ++r, p += W) {
+                const float v = *p;
+                if (v == v) *p = fmaxf(v, l);
+            }
+        }
+        return;
+    }
+    if (flat[t] == FLAT_NONE) return;
+    const float level = __builtin_bit_cast(float, flat[t]);
     if (lane < 2 || lane > FT - 1) return;
     float *p = wg + (size_t)(ty * FT + 2) * W + tx * FT + lane;
     for (int r = 2; r <= FT - 1; ++r, p += W) *p = level;
@@ -917,9 +974,6 @@ __global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int W, int ti
 // Measured on the bench raster (16384^2 "rough"): 67 % of the hub levels and 53 % of the raised
 // cells are exact from the start, mean excess 0.13 m; 3.5 visits per tile instead of 6.6.
 // ---------------------------------------------------------------------------
-constexpr int HUB_EDGE = 4 * WN;        // floats per tile: N row, S row (lane = column),
-                                        // W column, E column (lane = row) of d on the tile's rim
-constexpr float HUB_BIG = 3.0e38f;      // a wall of the hub raster (finite: not nodata)
 
 template <int ITERS>
 __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict__ zg,
@@ -945,7 +999,7 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
     for (int r = 0; r < WN; ++r) w[r] = HDEM_INF;
     if (nan_any) {
         // pinned cells of the fill -- nodata's 8 neighbours -- are the sources of this tile
-        unsigned long long a = 0, b = __ballot(z[0] != z[0]), pins = 0;
+        unsigned long long a = __ballot(z[0] != z[0]), b = __ballot(z[1] != z[1]), pins = 0;
 #pragma unroll
         for (int r = 1; r <= FT; ++r) {
             const unsigned long long c = __ballot(z[r + 1] != z[r + 1]);
@@ -1036,7 +1090,8 @@ __device__ __forceinline__ float seam_cost(float a, float b, int lane)
 
 // The hub raster: node, east and south crossing of every tile (and the crossings to the raster
 // ring for the tiles next to it).
-__global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__ zg, int H, int W,
+__global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__ zg,
+                                                       float *__restrict__ wg, int H, int W,
                                                        int tiles_x, int tiles_y,
                                                        const float *__restrict__ edge,
                                                        const float *__restrict__ node,
@@ -1049,13 +1104,20 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
     const float mine_n = e[lane], mine_s = e[WN + lane], mine_w = e[2 * WN + lane],
                 mine_e = e[3 * WN + lane];
     // ring cells next to my rim (walls where nodata or outside the raster)
+    // (and W's ring <- Z: the fill's Dirichlet boundary, written by the tiles next to it)
     auto ring_col = [&](int xr) {
         const int y = y0 + lane;
-        return y <= H - 1 ? fminf(zg[(size_t)y * W + xr], HDEM_INF) : HDEM_INF;
+        if (y > H - 1) return HDEM_INF;
+        const float v = zg[(size_t)y * W + xr];
+        wg[(size_t)y * W + xr] = v;
+        return fminf(v, HDEM_INF);
     };
     auto ring_row = [&](int yr) {
         const int xx = x0 + lane;
-        return xx <= W - 1 ? fminf(zg[(size_t)yr * W + xx], HDEM_INF) : HDEM_INF;
+        if (xx > W - 1) return HDEM_INF;
+        const float v = zg[(size_t)yr * W + xx];
+        wg[(size_t)yr * W + xx] = v;
+        return fminf(v, HDEM_INF);
     };
     auto big = [](float v) { return v < HUB_BIG ? v : HUB_BIG; };
     const float other_e = tx + 1 < tiles_x ? edge[(size_t)(t + 1) * HUB_EDGE + 2 * WN + lane]
@@ -1079,50 +1141,6 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
     }
 }
 
-// W <- max(d, level of the tile's hub) on the tile interiors (d as hub_dist_kernel left it;
-// pinned cells and the tiles that are outlets keep d), Z on the raster ring.
-__global__ __launch_bounds__(INIT_NT) void hub_apply_kernel(const float *__restrict__ z,
-                                                          float *__restrict__ w, int H, int W,
-                                                          const float *__restrict__ lev, int cw)
-{
-    const int quads = (W + 3) / 4;
-    const size_t q = (size_t)blockIdx.x * INIT_NT + threadIdx.x;
-    if (q >= (size_t)H * quads) return;
-    const int y = (int)(q / quads), x = (int)(q % quads) * 4;
-    float *dst = w + (size_t)y * W + x;
-    const bool ring_row = y == 0 || y == H - 1;
-    const float *lrow = lev + (size_t)(2 * (ring_row ? 0 : (y - 1) / FT) + 1) * cw;
-    float v[4];
-    if (x + 4 <= W && !ring_row) {
-        const hdem_f4 m = hdem_ld4u(dst);
-        v[0] = m[0]; v[1] = m[1]; v[2] = m[2]; v[3] = m[3];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (x + k < W && !ring_row) ? dst[k] : 0.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int xx = x + k;
-        if (xx >= W) break;
-        if (ring_row || xx == 0 || xx == W - 1) {
-            v[k] = z[(size_t)y * W + xx];
-        } else {
-            float l = lrow[2 * ((xx - 1) / FT) + 1];
-            if (l >= HUB_BIG) l = HDEM_INF;
-            // (a NaN level: the tile is an outlet, d is its bound; a NaN d: nodata, kept)
-            if (l == l && v[k] == v[k]) v[k] = fmaxf(v[k], l);
-        }
-    }
-    if (x + 4 <= W) {
-        const hdem_f4 m = {v[0], v[1], v[2], v[3]};
-        hdem_st4u(dst, m);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (x + k < W) dst[k] = v[k];
-    }
-}
-
 // ROLE only names the launch (0: the raster itself, 1: the coarse pre-solve of a larger
 // raster) so that profilers list the two apart.
 template <bool HAS_EPS, int ROLE>
@@ -1133,7 +1151,9 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
                                                           int *pend, int *error,
                                                           unsigned long long *stats,
                                                           long long budget_ticks, int soft,
-                                                          int *flat, int *zmax)
+                                                          int *flat, int *zmax,
+                                                          const float *__restrict__ hub_lev,
+                                                          int *applied)
 {
     __shared__ float T[WN * TS];
     const int G = gridDim.x, b = blockIdx.x;
@@ -1172,13 +1192,44 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
         // flat[t] / zmax[t] belong to whoever runs the tile; agent-scope accesses, handed on
         // with the tile's state word like the tile itself
         float flat_level = HDEM_INF;
+        // (hub start) which of the nine tiles under the window have had their first visit?
+        // Read BEFORE the window: a tile found visited had its cells in memory before its
+        // mark; a tile found unvisited has its cells raised to its start bound, which is right
+        // for d and harmless for newer values.  Rides on the round trip of the flat level.
+        hub_bounds hb;
+        bool use_hb = false, first_visit = false;
+        const int fb_raw = HAS_EPS ? FLAT_NONE : ld_relaxed(flat + t);
+        if (!HAS_EPS && hub_lev) {
+            const int k9 = threadIdx.x < 9 ? (int)threadIdx.x : 4;
+            const int ny = ty + k9 / 3 - 1, nx = tx + k9 % 3 - 1;
+            const bool there = threadIdx.x < 9 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x;
+            float l = -HDEM_INF;
+            int seen = 1;
+            if (there) {
+                seen = ld_relaxed(applied + ny * tiles_x + nx);
+                l = hub_lev[(size_t)(2 * ny + 1) * (2 * tiles_x + 1) + 2 * nx + 1];
+            }
+            // (a NaN level: the tile is an outlet of the hub graph, its d is its bound)
+            l = (seen || l != l) ? -HDEM_INF : (l >= HUB_BIG ? HDEM_INF : l);
+            first_visit = __builtin_amdgcn_readlane(seen, 4) == 0;
+            use_hb = first_visit || __ballot(l > -HDEM_INF) != 0;
+            if (use_hb) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    hb.lv[k] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), k));
+                hb.mine = first_visit;
+            }
+            asm volatile("" ::: "memory");      // (the window loads stay behind the marks)
+        }
         if (!HAS_EPS) {
-            const int fb = __builtin_amdgcn_readfirstlane(ld_relaxed(flat + t));
+            const int fb = __builtin_amdgcn_readfirstlane(fb_raw);
             if (fb != FLAT_NONE) {
                 flat_level = __builtin_bit_cast(float, fb);
                 const float zm = __builtin_bit_cast(
                     float, __builtin_amdgcn_readfirstlane(ld_relaxed(zmax + t)));
-                const flat_result f = flat_visit(wg, H, W, ty, tx, flat_level, zm);
+                const flat_result f = flat_visit(wg, H, W, ty, tx, flat_level, zm,
+                                                 use_hb ? &hb : nullptr);
                 if (f.handled) {
                     if (f.changed) {
                         if (threadIdx.x == 0)
@@ -1202,7 +1253,14 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
             }
         }
         const visit_result v = tile_visit<HAS_EPS, true>(zg, wg, H, W, eps, ty, tx, T, nullptr,
-                                                         flat_level);
+                                                         flat_level, use_hb ? &hb : nullptr);
+        if (first_visit) {
+            // the tile's cells are in memory before its mark, the mark before its state word
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0)
+                __hip_atomic_store(applied + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!HAS_EPS && (v.flat_bits != FLAT_NONE || flat_level < HDEM_INF)) {
             if (threadIdx.x == 0) {
                 __hip_atomic_store(flat + t, v.flat_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1403,7 +1461,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     const size_t stat_ints = (size_t)ws->G * STAT_WORDS * 2;
     const size_t head = HEAD_INTS;                                 // error + pad (128 B)
     const size_t ints = head + stat_ints + PEND_SHARDS * PEND_STRIDE + n + 2 * gs +
-                        (size_t)max_rounds + 32 + 2 * n;
+                        (size_t)max_rounds + 32 + 3 * n;
     const size_t bytes = ints * sizeof(int);
     if (ctx->fill_ws_bytes < bytes) {
         if (ctx->fill_ws) {
@@ -1424,7 +1482,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
         HDEM_HIP_CHECK(hipHostMalloc((void **)&ctx->host_counts, host_ints * sizeof(int32_t)));
         ctx->host_counts_len = host_ints;
     }
-    // Layout: [error | stats | any] [pend | state] [tile_key | prio] [flat | zmax] -- what is
+    // Layout: [error | stats | any | applied] [pend | state] [tile_key | prio] [flat | zmax] -- what is
     // zeroed sits together and what is set to 0x7f.. sits together, so that a call costs two
     // fill launches, not seven (each one is a kernel of its own, ~4 us on the stream).
     int *base = (int *)ctx->fill_ws;
@@ -1432,7 +1490,8 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     ws->error = base;
     ws->stats = (unsigned long long *)(base + head);               // 8-byte aligned
     ws->any = base + head + stat_ints;
-    ws->pend = ws->any + any_ints;
+    ws->applied = ws->any + any_ints;
+    ws->pend = ws->applied + n;
     ws->state = ws->pend + pend_ints;
     ws->tile_key = ws->state + gs;
     ws->prio = ws->tile_key + n;
@@ -1441,7 +1500,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     // error, stats, any = 0 and the flat levels reset (they live inside one asynchronous
     // launch and are written out behind it); a resumed worklist keeps pend / state /
     // tile_key / prio of the last slice
-    const size_t zeros = head + stat_ints + any_ints + (*resume ? 0 : pend_ints + gs);
+    const size_t zeros = head + stat_ints + any_ints + n + (*resume ? 0 : pend_ints + gs);
     HDEM_HIP_CHECK(hipMemsetAsync(base, 0, zeros * sizeof(int), ctx->stream));
     int *sevens = *resume ? ws->flat : ws->tile_key;
     HDEM_HIP_CHECK(hipMemsetAsync(sevens, 0x7f, (size_t)(ws->zmax + n - sevens) * sizeof(int),
@@ -1591,7 +1650,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_HUB, (int64_t)H * W);
             hipLaunchKernelGGL(hub_dist_kernel<2>, dim3(ws.ntiles), dim3(NT), 0, st, z, w, H, W,
                                ws.tiles_x, hub_edge, hub_node);
-            hipLaunchKernelGGL(hub_edges_kernel, dim3(ws.ntiles), dim3(NT), 0, st, z, H, W,
+            hipLaunchKernelGGL(hub_edges_kernel, dim3(ws.ntiles), dim3(NT), 0, st, z, w, H, W,
                                ws.tiles_x, ws.tiles_y, hub_edge, hub_node, hub_cr);
         }
         HDEM_HIP_CHECK(hipGetLastError());
@@ -1613,10 +1672,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         ctx->fill_last_z = z;
         ctx->fill_last_out = w;
         ctx->fill_resumable = ctx->fill_quiescent = false;
-        hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
-        const size_t n = (size_t)H * ((W + 3) / 4);
-        hipLaunchKernelGGL(hub_apply_kernel, dim3((unsigned)((n + INIT_NT - 1) / INIT_NT)),
-                           dim3(INIT_NT), 0, st, z, w, H, W, hub_lev, hub_cw);
+        // (no pass over the raster for max(d, level): every tile makes it on its first visit)
     } else if (!warm) {
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
         const size_t n = (size_t)((H + INIT_ROWS - 1) / INIT_ROWS) * ((W + 3) / 4);
@@ -1643,7 +1699,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                                         : 20000000ll + (long long)ws.ntiles * 200ll;
         int soft = slice_us > 0;
         // (tests: cut the asynchronous phase short so that the passes behind it have work)
-        if (const char *tb = getenv("HDEM_FILL_TEST_BUDGET_US")) {
+        // (not the pre-solve of a start raster: that one is to run as it always does)
+        if (const char *tb = ctx->in_coarse_presolve ? nullptr : getenv("HDEM_FILL_TEST_BUDGET_US")) {
             budget = atoll(tb) * 100ll;
             soft = 1;
         }
@@ -1651,21 +1708,24 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         if (eps != 0.0f)
             hipLaunchKernelGGL((fill_async_kernel<true, 0>), dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
+                               hub_lev, ws.applied);
         else if (ctx->in_coarse_presolve)
             hipLaunchKernelGGL((fill_async_kernel<false, 1>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
+                               hub_lev, ws.applied);
         else
             hipLaunchKernelGGL((fill_async_kernel<false, 0>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
-                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax);
+                               ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
+                               hub_lev, ws.applied);
     }
     if (did_async && eps == 0.0f) {
         // tiles that ended the launch flat have only their edge lines in memory
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_FLAT, 0);
-        hipLaunchKernelGGL(flat_store_kernel, dim3(ws.ntiles), dim3(NT), 0, st, w, W, ws.tiles_x,
-                           ws.ntiles, ws.flat);
+        hipLaunchKernelGGL(flat_store_kernel, dim3(ws.ntiles), dim3(NT), 0, st, w, H, W, ws.tiles_x,
+                           ws.ntiles, ws.flat, hub_lev, ws.applied);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------

@@ -529,6 +529,49 @@ def test_own_coarse_pre_solve_small_raster(monkeypatch):
         assert np.array_equal(np.nan_to_num(plain, nan=-1), np.nan_to_num(want, nan=-1))
 
 
+@pytest.mark.parametrize("shape,variant,holes", [
+    ((700, 900), "rough", 0), ((700, 900), "srtm", 0), ((64, 33), "rough", 0),
+    ((333, 1100), "rough", 1), ((3, 3), "rough", 0), ((5, 200), "rough", 0),
+    ((1000, 66), "srtm", 1), ((126, 126), "rough", 0), ((127, 189), "rough", 2),
+    ((1500, 1300), "rough", 3),
+])
+def test_hub_start_gives_the_same_bits(monkeypatch, shape, variant, holes):
+    """Round 3's start values (hub graph: in-tile path costs to a hub per tile + the hub
+    raster filled exactly, hdem_sinkfill.hip) on rasters with partial tiles, ties, nodata
+    blocks -- a tile with a nodata fringe is an outlet of the graph -- and whole tiles of
+    nodata; forced on below the size it normally starts at."""
+    monkeypatch.setenv("HDEM_HUB_MIN_TILES", "1")
+    z = oracle.synth_dem(*shape, variant=variant)
+    if holes >= 1:
+        z[shape[0] // 2, shape[1] // 2] = np.nan
+    if holes >= 2:
+        z[60:70, 60:64] = np.nan                           # across a tile corner
+    if holes >= 3:
+        z[620:760, 300:500] = np.nan                       # holds whole tiles
+        z[0:5, 1000:1100] = np.nan                         # on the raster ring
+    want = c_oracle.sinkfill_pflood(z)
+    ctx = backend.context()
+    ctx.profile(True)
+    ctx.profile_reset()
+    zd = backend.DeviceRaster.from_host(z)
+    wd, codes, st = backend.sinkfill_d8_dev(zd)
+    used = ctx.profile_get(backend.K_FILL_HUB)["launches"]
+    ctx.profile(False)
+    assert used == (1 if min(shape) >= 3 and st["tiles"] >= 1 else 0)
+    assert st["converged"] and st["rounds"] == 0
+    assert np.array_equal(wd.to_host(), want, equal_nan=True)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    # the start values themselves are upper bounds of the fill: cut the relaxation short
+    # right after them (no visit, no certifying pass) and look
+    monkeypatch.setenv("HDEM_FILL_TEST_BUDGET_US", "0")
+    ud, _ = backend.sinkfill_dev(zd, flags=backend.FILL_INIT | backend.FILL_NO_VERIFY)
+    u = ud.to_host()
+    ok = np.isnan(want) | (u >= want)
+    assert ok.all(), f"{int((~ok).sum())} start values below the fill"
+    for r in (zd, wd, codes, ud):
+        r.free()
+
+
 def test_time_sliced_fill_resumes_to_the_same_bits():
     """INIT with a short time slice leaves tiles queued; RESUME continues the same
     worklist; the result and a final certifying pass agree with the oracle."""
@@ -733,7 +776,12 @@ def _crater(n, rim, passes, island_nan=False, seed=5):
     (((0.5, 33.0),), True),                       # nodata in the bowl: an outlet, the lake drains
     (((0.5, 24.0),), False),                      # a gap below the bowl's slopes: the lake
 ])                                                # shrinks to the bottom, tiles leave the flat path
-def test_sinkfill_lakes_take_the_flat_path_and_stay_exact(passes, island):
+@pytest.mark.parametrize("hub", [False, True])
+def test_sinkfill_lakes_take_the_flat_path_and_stay_exact(passes, island, hub, monkeypatch):
+    # (round 3: from the hub start the lake has its level before the first visit and no tile
+    # is ever visited as a flat one -- the flat path is exercised from the +inf start)
+    if not hub:
+        monkeypatch.setenv("HDEM_FILL_HUB", "0")
     z = _crater(1500, 40.0, passes, island)
     zd = backend.DeviceRaster.from_host(z)
     wd, codes, st = backend.sinkfill_d8_dev(zd)
@@ -742,7 +790,8 @@ def test_sinkfill_lakes_take_the_flat_path_and_stay_exact(passes, island):
     assert np.array_equal(wd.to_host(), want, equal_nan=True)
     assert np.array_equal(codes.to_host(), c_oracle.d8(want))
     if not island:
-        assert st["visits_flat"] > 0              # the lake's tiles did take the short path
+        if not hub:
+            assert st["visits_flat"] > 0          # the lake's tiles did take the short path
         assert np.nanmax(want - z) > 3.0          # and there is a lake
     # a second fill into the same output (stale interiors of flat tiles from the first
     # call must not leak): same bits
@@ -757,6 +806,7 @@ def test_flat_path_with_the_coarse_start(monkeypatch):
     """The same lake above the size from which the fill starts from a coarse solve
     (threshold lowered so that the test stays small)."""
     monkeypatch.setenv("HDEM_COARSE_MIN_CELLS", "1000000")
+    monkeypatch.setenv("HDEM_FILL_HUB", "0")              # (the block-maximum start of rounds 1-2)
     z = _crater(1800, 40.0, ((0.3, 35.0), (0.7, 32.0)))
     wd, st = backend.sinkfill_dev(backend.DeviceRaster.from_host(z))
     assert np.array_equal(wd.to_host(), c_oracle.sinkfill_pflood(z))

@@ -38,10 +38,12 @@ def test_config2_4096_sinkfill_d8_bit_exact(built, variant):
     ctx.profile(True)
     ctx.profile_reset()
     wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z))
-    coarse_launches = ctx.profile_get(backend.K_FILL_COARSE)["launches"]
+    hub_launches = ctx.profile_get(backend.K_FILL_HUB)["launches"]
+    blockmax_launches = ctx.profile_get(backend.K_BLOCKMAX)["launches"]
     ctx.profile(False)
     assert st["converged"] and st["async_timed_out"] == 0
-    assert coarse_launches == 0                  # below COARSE_MIN_CELLS: the +inf start
+    assert hub_launches == 1 and blockmax_launches == 0      # round 3: the hub start
+    assert st["tile_visits"] < 8 * st["tiles"]               # (12 per tile from +inf)
     want = c_oracle.sinkfill_pflood(z)
     assert np.array_equal(wd.to_host(), want)
     assert np.array_equal(codes.to_host(), c_oracle.d8(want))
