@@ -978,11 +978,13 @@ __global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int H, int W,
 template <int ITERS>
 __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict__ zg,
                                                         float *__restrict__ wg, int H, int W,
-                                                        int tiles_x, float *__restrict__ edge,
+                                                        int tiles_x, int ntiles,
+                                                        float *__restrict__ edge,
                                                         float *__restrict__ node)
 {
     __shared__ float T[WN * TS];
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * FT, x0 = tx * FT, x = x0 + lane, xc = min(x, W - 1);
     float z[WN], w[WN];
@@ -1072,6 +1074,7 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
         for (int r = 1; r <= FT; ++r)
             if (r <= lr)
                 wg[(size_t)(y0 + r) * W + x] = z[r] == HDEM_INF ? __builtin_nanf("") : w[r];
+    }
     }
 }
 
@@ -1648,8 +1651,25 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     if (hub_lev) {
         {
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_HUB, (int64_t)H * W);
-            hipLaunchKernelGGL(hub_dist_kernel<2>, dim3(ws.ntiles), dim3(NT), 0, st, z, w, H, W,
-                               ws.tiles_x, hub_edge, hub_node);
+            // (HDEM_HUB_ITERS / HDEM_HUB_WGS: experiments)
+            const int hub_iters = getenv("HDEM_HUB_ITERS") ? atoi(getenv("HDEM_HUB_ITERS")) : 3;
+            // one workgroup per tile: a resident grid of 8 per CU walking the tiles was measured
+            // at 0.77 against 0.64 ms (HDEM_HUB_WGS: that grid, per CU)
+            const int hub_grid = getenv("HDEM_HUB_WGS")
+                                     ? std::min(ws.ntiles, ctx->num_cus * atoi(getenv("HDEM_HUB_WGS")))
+                                     : ws.ntiles;
+            if (hub_iters >= 4)
+                hipLaunchKernelGGL(hub_dist_kernel<4>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
+                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
+            else if (hub_iters == 3)
+                hipLaunchKernelGGL(hub_dist_kernel<3>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
+                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
+            else if (hub_iters <= 1)
+                hipLaunchKernelGGL(hub_dist_kernel<1>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
+                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
+            else
+                hipLaunchKernelGGL(hub_dist_kernel<2>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
+                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
             hipLaunchKernelGGL(hub_edges_kernel, dim3(ws.ntiles), dim3(NT), 0, st, z, w, H, W,
                                ws.tiles_x, ws.tiles_y, hub_edge, hub_node, hub_cr);
         }

@@ -15,4 +15,4 @@ for rep in range(6):
     g = lambda k: ctx.profile_get(k)['ms']
     print(f"step {dt*1e3:.2f} ms: hub {g(B.K_FILL_HUB):.3f} blockmax {g(B.K_BLOCKMAX):.3f} coarse {g(B.K_FILL_COARSE):.3f} "
           f"init/apply {g(B.K_FILL_INIT):.3f} tile {g(B.K_FILL_TILE):.3f} flat {g(B.K_FILL_FLAT):.3f} certify {g(B.K_FILL_ROUND):.3f}; visits {st['tile_visits']} "
-          f"({st['tile_visits']/st['tiles']:.2f}/tile) unchanged {st['visits_unchanged']} flat {st['visits_flat']}", flush=True)
+          f"({st['tile_visits']/st['tiles']:.2f}/tile) unchanged {st['visits_unchanged']} flat {st['visits_flat']} iterations {st['iterations']}", flush=True)
