@@ -71,6 +71,9 @@ SIGNATURES = {
     "hdem_synchronize": [_vp],
     "hdem_set_fill_slice_us": [_vp, _i],
     "hdem_set_fill_coarse_start": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_fill_hub_prepare_dev": [_vp, _vp, _i, _i, _i, _vp],
+    "hdem_fill_hub_raster_dev": [_vp, _vp],
+    "hdem_set_fill_hub_levels": [_vp, _vp],
     "hdem_malloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
     "hdem_free": [_vp, _vp],
     "hdem_trim": [_vp, _c.POINTER(_c.c_size_t)],
@@ -227,6 +230,18 @@ class Context:
         self.check(self.lib.hdem_set_fill_coarse_start(
             self.handle, ctypes.c_void_p(coarse_ptr or 0), int(ch), int(cw), int(block),
             ctypes.c_void_p(row_map_ptr or 0)))
+
+    def fill_hub_prepare(self, z_ptr, h, w, flags, w_ptr):
+        """``hdem_fill_hub_prepare_dev``: d of a row block into the interior of ``w``."""
+        self.check(self.lib.hdem_fill_hub_prepare_dev(
+            self.handle, ctypes.c_void_p(z_ptr), int(h), int(w), int(flags), ctypes.c_void_p(w_ptr)))
+
+    def fill_hub_raster(self, out_ptr):
+        """``hdem_fill_hub_raster_dev``: the prepared block's hub raster into ``out_ptr``."""
+        self.check(self.lib.hdem_fill_hub_raster_dev(self.handle, ctypes.c_void_p(out_ptr)))
+
+    def set_fill_hub_levels(self, levels_ptr):
+        self.check(self.lib.hdem_set_fill_hub_levels(self.handle, ctypes.c_void_p(levels_ptr or 0)))
 
     def set_stream(self, stream_ptr):
         self.check(self.lib.hdem_set_stream(self.handle,

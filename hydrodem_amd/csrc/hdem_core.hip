@@ -82,9 +82,11 @@ extern "C" int hdem_shutdown(hdem_ctx *ctx)
     for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
     for (auto ev : ctx->pool_events) (void)hipEventDestroy(ev);
     hdem_fourier_release(ctx);
-    if (ctx->fill_ws) (void)hipFree(ctx->fill_ws);
+    for (void *b : ctx->fill_ws)
+        if (b) (void)hipFree(b);
     if (ctx->coarse_buf) (void)hipFree(ctx->coarse_buf);
-    if (ctx->hub_buf) (void)hipFree(ctx->hub_buf);
+    for (void *b : ctx->hub_buf)
+        if (b) (void)hipFree(b);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -190,12 +192,13 @@ extern "C" int hdem_trim(hdem_ctx *ctx, size_t *released)
         ctx->coarse_buf = nullptr;
         ctx->coarse_bytes = 0;
     }
-    if (ctx->hub_buf) {
-        bytes += ctx->hub_bytes;
-        (void)hipFree(ctx->hub_buf);
-        ctx->hub_buf = nullptr;
-        ctx->hub_bytes = 0;
-    }
+    for (int k = 0; k < 2; ++k)
+        if (ctx->hub_buf[k]) {
+            bytes += ctx->hub_bytes[k];
+            (void)hipFree(ctx->hub_buf[k]);
+            ctx->hub_buf[k] = nullptr;
+            ctx->hub_bytes[k] = 0;
+        }
     if (released) *released = bytes;
     return HDEM_OK;
 }

@@ -64,8 +64,8 @@ struct hdem_ctx {
     std::vector<hipEvent_t> event_pool;
     hdem_kernel_stat stats[HDEM_K_COUNT] = {};
     // sink-fill workspace (grown on demand, reused across calls)
-    void *fill_ws = nullptr;
-    size_t fill_ws_bytes = 0;
+    void *fill_ws[3] = {nullptr, nullptr, nullptr};   // [hub_depth]
+    size_t fill_ws_bytes[3] = {0, 0, 0};
     int fill_slice_us = 0;             // 0: run the asynchronous phase to convergence
     int fill_last_h = 0, fill_last_w = 0;   // problem the worklist in fill_ws belongs to
     const void *fill_last_z = nullptr, *fill_last_out = nullptr;
@@ -80,9 +80,17 @@ struct hdem_ctx {
     bool in_coarse_presolve = false;   // the fill in progress is that pre-solve
     uint8_t *fill_d8 = nullptr;        // D8 raster the certifying pass of the next fill writes
     bool fill_d8_done = false;         // ... and whether it did
+    bool fill_d8_ring_done = false;    // ... the raster ring included (the certifying stream)
     size_t coarse_bytes = 0;
-    void *hub_buf = nullptr;           // hub start of the sink fill: rim lines, hub raster
-    size_t hub_bytes = 0;
+    void *hub_buf[2] = {nullptr, nullptr};   // hub start of the sink fill: rim lines, hub raster
+    size_t hub_bytes[2] = {0, 0};            // ([1]: of the hub raster's own fill)
+    int hub_depth = 0;                       // 0: a caller's fill, 1: of a hub raster, 2: of its raster
+    // ... prepared for a row-block partition (hdem_fill_hub_prepare_dev), and the levels the
+    // partition worked out for the next INIT fill of that block
+    const float *hub_prep_z = nullptr;
+    float *hub_prep_w = nullptr;
+    int hub_prep_h = 0, hub_prep_cols = 0, hub_prep_flags = 0;
+    const float *hub_levels_given = nullptr;
     void *arena = nullptr;             // scratch of the multi-kernel chains, grown on demand
     size_t arena_bytes = 0;
     hdem_fourier_state *fourier = nullptr;

@@ -65,7 +65,8 @@ constexpr int COARSE_SHIFT = 4;    // own coarse start: 16 x 16 blocks ...
 constexpr int HUB_EDGE = 4 * WN;        // hub start, floats per tile: N row, S row (lane = column),
                                         // W column, E column (lane = row) of d on the tile's rim
 constexpr float HUB_BIG = 3.0e38f;      // a wall of the hub raster (finite: not nodata)
-constexpr int HUB_MIN_TILES = 256;     // hub start (below) from this many tiles on (~1000^2 cells)
+constexpr int HUB_MIN_TILES = 64;       // hub start from this many tiles on (512^2 cells: measured)
+constexpr int HUB_MIN_TILES_NESTED = 36;   // ... of a hub raster's own fill     // hub start (below) from this many tiles on (~1000^2 cells)
 constexpr int COARSE_MIN_CELLS = 6000 * 6000;   // ... from this raster size on (below, the
                                    // two extra launches cost what they save)
 constexpr int PEND_SHARDS = 64;    // one per lane of the polling wave
@@ -1098,7 +1099,8 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
                                                        int tiles_x, int tiles_y,
                                                        const float *__restrict__ edge,
                                                        const float *__restrict__ node,
-                                                       float *__restrict__ cr)
+                                                       float *__restrict__ cr, int ghost_top,
+                                                       int ghost_bottom)
 {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -1115,9 +1117,17 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
         wg[(size_t)y * W + xr] = v;
         return fminf(v, HDEM_INF);
     };
-    auto ring_row = [&](int yr) {
+    // Row-block partition: a ghost row is a row of the neighbouring block, and the caller has
+    // put that block's d there (its path costs to ITS hubs): the crossing then joins my hub to
+    // the hub of the neighbour's tile with the same column range -- the two tilings share their
+    // columns -- so the two cells that belong to the tile columns beside mine stay out.
+    auto ring_row = [&](int yr, int ghost) {
         const int xx = x0 + lane;
         if (xx > W - 1) return HDEM_INF;
+        if (ghost) {
+            const float v = wg[(size_t)yr * W + xx];
+            return (lane == 0 || lane == WN - 1) ? HDEM_INF : fminf(v, HDEM_INF);
+        }
         const float v = zg[(size_t)yr * W + xx];
         wg[(size_t)yr * W + xx] = v;
         return fminf(v, HDEM_INF);
@@ -1126,11 +1136,11 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
     const float other_e = tx + 1 < tiles_x ? edge[(size_t)(t + 1) * HUB_EDGE + 2 * WN + lane]
                                            : ring_col(W - 1);
     const float other_s = ty + 1 < tiles_y ? edge[(size_t)(t + tiles_x) * HUB_EDGE + lane]
-                                           : ring_row(H - 1);
+                                           : ring_row(H - 1, ghost_bottom);
     const float ce = seam_cost(mine_e, other_e, lane), cs = seam_cost(mine_s, other_s, lane);
     float cwest = HDEM_INF, cnorth = HDEM_INF;
     if (tx == 0) cwest = seam_cost(mine_w, ring_col(0), lane);
-    if (ty == 0) cnorth = seam_cost(mine_n, ring_row(0), lane);
+    if (ty == 0) cnorth = seam_cost(mine_n, ring_row(0, ghost_top), lane);
     if (lane == 0) {
         float *row = cr + (size_t)(2 * ty + 1) * cw + 2 * tx + 1;
         const float nz = node[t];
@@ -1466,15 +1476,19 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     const size_t ints = head + stat_ints + PEND_SHARDS * PEND_STRIDE + n + 2 * gs +
                         (size_t)max_rounds + 32 + 3 * n;
     const size_t bytes = ints * sizeof(int);
-    if (ctx->fill_ws_bytes < bytes) {
-        if (ctx->fill_ws) {
+    // (a workspace per nesting depth: the fill of a hub raster runs in the middle of the fill it
+    // starts, whose workspace is set up already)
+    void *&ws_buf = ctx->fill_ws[ctx->hub_depth];
+    size_t &ws_bytes = ctx->fill_ws_bytes[ctx->hub_depth];
+    if (ws_bytes < bytes) {
+        if (ws_buf) {
             HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            HDEM_HIP_CHECK(hipFree(ctx->fill_ws));
-            ctx->fill_ws = nullptr;
-            ctx->fill_ws_bytes = 0;
+            HDEM_HIP_CHECK(hipFree(ws_buf));
+            ws_buf = nullptr;
+            ws_bytes = 0;
         }
-        if (int rc = hdem_raw_alloc(ctx, bytes, &ctx->fill_ws)) return rc;
-        ctx->fill_ws_bytes = bytes;
+        if (int rc = hdem_raw_alloc(ctx, bytes, &ws_buf)) return rc;
+        ws_bytes = bytes;
         *resume = false;                                           // the worklist went with it
     }
     const size_t host_ints = std::max(std::max(head + stat_ints, (size_t)max_rounds + 32),
@@ -1488,7 +1502,7 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     // Layout: [error | stats | any | applied] [pend | state] [tile_key | prio] [flat | zmax] -- what is
     // zeroed sits together and what is set to 0x7f.. sits together, so that a call costs two
     // fill launches, not seven (each one is a kernel of its own, ~4 us on the stream).
-    int *base = (int *)ctx->fill_ws;
+    int *base = (int *)ws_buf;
     const size_t any_ints = (size_t)max_rounds + 32, pend_ints = PEND_SHARDS * PEND_STRIDE;
     ws->error = base;
     ws->stats = (unsigned long long *)(base + head);               // 8-byte aligned
@@ -1511,7 +1525,126 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     return HDEM_OK;
 }
 
+struct hub_bufs {
+    float *edge, *node, *cr, *lev;
+    int ch, cw, tiles_x, tiles_y;
+};
+
+// The hub start's device buffers (kept in the context, grown on demand): rim lines and hub
+// elevation of every tile, the hub raster and its filled twin.
+int hub_alloc(hdem_ctx *ctx, int depth, int H, int W, hub_bufs *hb)
+{
+    void *&buf = ctx->hub_buf[depth];
+    size_t &buf_bytes = ctx->hub_bytes[depth];
+    hb->tiles_x = (W - 2 + FT - 1) / FT;
+    hb->tiles_y = (H - 2 + FT - 1) / FT;
+    hb->ch = 2 * hb->tiles_y + 1;
+    hb->cw = 2 * hb->tiles_x + 1;
+    const size_t nt = (size_t)hb->tiles_x * hb->tiles_y, cells = (size_t)hb->ch * hb->cw;
+    const size_t need = (nt * (HUB_EDGE + 1) + 2 * cells) * sizeof(float);
+    if (buf_bytes < need) {
+        if (buf) {
+            HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            HDEM_HIP_CHECK(hipFree(buf));
+            buf = nullptr;
+            buf_bytes = 0;
+        }
+        if (int rc = hdem_raw_alloc(ctx, need, &buf)) return rc;
+        buf_bytes = need;
+    }
+    hb->edge = (float *)buf;
+    hb->node = hb->edge + nt * HUB_EDGE;
+    hb->cr = hb->node + nt;
+    hb->lev = hb->cr + cells;
+    return HDEM_OK;
+}
+
+void hub_launch_dist(hdem_ctx *ctx, const float *z, float *w, int H, int W, const hub_bufs &hb)
+{
+    const int ntiles = hb.tiles_x * hb.tiles_y;
+    // (HDEM_HUB_ITERS / HDEM_HUB_WGS: experiments)
+    const int iters = getenv("HDEM_HUB_ITERS") ? atoi(getenv("HDEM_HUB_ITERS")) : 3;
+    // one workgroup per tile: a resident grid of 8 per CU walking the tiles was measured
+    // at 0.77 against 0.64 ms (HDEM_HUB_WGS: that grid, per CU)
+    const int grid = getenv("HDEM_HUB_WGS") ? std::min(ntiles, ctx->num_cus * atoi(getenv("HDEM_HUB_WGS")))
+                                            : ntiles;
+    hipStream_t st = ctx->stream;
+    if (iters >= 4)
+        hipLaunchKernelGGL(hub_dist_kernel<4>, dim3(grid), dim3(NT), 0, st, z, w, H, W, hb.tiles_x,
+                           ntiles, hb.edge, hb.node);
+    else if (iters == 3)
+        hipLaunchKernelGGL(hub_dist_kernel<3>, dim3(grid), dim3(NT), 0, st, z, w, H, W, hb.tiles_x,
+                           ntiles, hb.edge, hb.node);
+    else if (iters <= 1)
+        hipLaunchKernelGGL(hub_dist_kernel<1>, dim3(grid), dim3(NT), 0, st, z, w, H, W, hb.tiles_x,
+                           ntiles, hb.edge, hb.node);
+    else
+        hipLaunchKernelGGL(hub_dist_kernel<2>, dim3(grid), dim3(NT), 0, st, z, w, H, W, hb.tiles_x,
+                           ntiles, hb.edge, hb.node);
+}
+
+void hub_launch_edges(hdem_ctx *ctx, const float *z, float *w, int H, int W, int flags,
+                      const hub_bufs &hb)
+{
+    hipLaunchKernelGGL(hub_edges_kernel, dim3(hb.tiles_x * hb.tiles_y), dim3(NT), 0, ctx->stream, z,
+                       w, H, W, hb.tiles_x, hb.tiles_y, hb.edge, hb.node, hb.cr,
+                       flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM);
+}
+
 }  // namespace
+
+// ---- hub start of a row-block partition (hydrodem_amd/partition.py) -------------------------
+// The ranks build ONE hub graph: every rank makes the d of its block (prepare), swaps the seam
+// rows of d with its neighbours into its ghost rows, makes its hub raster (crossings to a ghost
+// row join its hubs to the neighbour's), the rasters are stacked and filled by every rank, and
+// the local fill then starts from the levels of the rank's own part (set_fill_hub_levels).
+extern "C" int hdem_fill_hub_prepare_dev(hdem_ctx *ctx, const float *z, int H, int W, int flags,
+                                         float *w)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(z, w, H, W)) return rc;
+    HDEM_REQUIRE(H >= 3 && W >= 3, HDEM_ERR_BAD_ARG, "hub start needs an interior, got %d x %d", H, W);
+    HDEM_REQUIRE(z != w, HDEM_ERR_BAD_ARG, "sink fill cannot run in place");
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    hub_bufs hb;
+    if (int rc = hub_alloc(ctx, 0, H, W, &hb)) return rc;
+    {
+        hdem_scoped_timer tm(ctx, HDEM_K_FILL_HUB, (int64_t)H * W);
+        hub_launch_dist(ctx, z, w, H, W, hb);
+    }
+    HDEM_HIP_CHECK(hipGetLastError());
+    ctx->hub_prep_z = z;
+    ctx->hub_prep_w = w;
+    ctx->hub_prep_h = H;
+    ctx->hub_prep_cols = W;
+    ctx->hub_prep_flags = flags & (HDEM_FILL_GHOST_TOP | HDEM_FILL_GHOST_BOTTOM);
+    ctx->hub_levels_given = nullptr;
+    return HDEM_OK;
+}
+
+extern "C" int hdem_fill_hub_raster_dev(hdem_ctx *ctx, float *raster)
+{
+    HDEM_REQUIRE(ctx && raster, HDEM_ERR_BAD_ARG, "null argument");
+    HDEM_REQUIRE(ctx->hub_prep_z, HDEM_ERR_BAD_ARG, "no prepared hub start (hdem_fill_hub_prepare_dev)");
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    hub_bufs hb;
+    if (int rc = hub_alloc(ctx, 0, ctx->hub_prep_h, ctx->hub_prep_cols, &hb)) return rc;
+    hub_launch_edges(ctx, ctx->hub_prep_z, ctx->hub_prep_w, ctx->hub_prep_h, ctx->hub_prep_cols,
+                     ctx->hub_prep_flags, hb);
+    HDEM_HIP_CHECK(hipGetLastError());
+    HDEM_HIP_CHECK(hipMemcpyAsync(raster, hb.cr, (size_t)hb.ch * hb.cw * sizeof(float),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    return HDEM_OK;
+}
+
+extern "C" int hdem_set_fill_hub_levels(hdem_ctx *ctx, const float *levels)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    HDEM_REQUIRE(!levels || ctx->hub_prep_z, HDEM_ERR_BAD_ARG,
+                 "no prepared hub start (hdem_fill_hub_prepare_dev)");
+    ctx->hub_levels_given = levels;
+    return HDEM_OK;
+}
 
 extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float eps,
                                      int max_rounds, int flags, float *w,
@@ -1547,35 +1680,36 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     const float *coarse = nullptr;
     const int *row_map = nullptr;
     int coarse_cw = 0, coarse_shift = 0;
-    // hub start (above): the single-GPU INIT default from HUB_MIN_TILES tiles on
+    // hub start (above): the single-GPU INIT default from HUB_MIN_TILES tiles on; or the levels
+    // a row-block partition worked out for this block (hdem_set_fill_hub_levels)
     const float *hub_lev = nullptr;
-    float *hub_edge = nullptr, *hub_node = nullptr, *hub_cr = nullptr;
-    int hub_ch = 0, hub_cw = 0;
-    if (!(flags & HDEM_FILL_WARM) && eps == 0.0f && !ctx->start_coarse && use_async &&
-        !(flags & (HDEM_FILL_NO_COARSE | HDEM_FILL_GHOST_TOP | HDEM_FILL_GHOST_BOTTOM)) &&
-        !(getenv("HDEM_FILL_HUB") && atoi(getenv("HDEM_FILL_HUB")) == 0) && H >= 3 && W >= 3) {
+    hub_bufs hubs = {};
+    const int hub_depth = ctx->hub_depth;
+    const float *const hub_given = ctx->hub_levels_given;
+    ctx->hub_levels_given = nullptr;
+    if (hub_given) {
+        HDEM_REQUIRE(!(flags & HDEM_FILL_WARM) && eps == 0.0f && use_async &&
+                         ctx->hub_prep_z == z && ctx->hub_prep_w == w && ctx->hub_prep_h == H &&
+                         ctx->hub_prep_cols == W,
+                     HDEM_ERR_BAD_ARG, "hub levels were set for another fill than this one");
+        ctx->hub_prep_z = nullptr;
+        hub_lev = hub_given;
+    } else if (!(flags & HDEM_FILL_WARM) && eps == 0.0f && !ctx->start_coarse && use_async &&
+               !(flags & (HDEM_FILL_GHOST_TOP | HDEM_FILL_GHOST_BOTTOM)) &&
+               // (NO_COARSE is the caller's "start from +inf"; the fill of a hub raster -- depth
+               // 1 -- carries it only to keep the block-maximum start out, and may take a hub
+               // start of its own, whose raster -- depth 2 -- is filled plainly)
+               (hub_depth == 1 || (hub_depth == 0 && !(flags & HDEM_FILL_NO_COARSE))) &&
+               !(getenv("HDEM_FILL_HUB") && atoi(getenv("HDEM_FILL_HUB")) == 0) && H >= 3 && W >= 3) {
         const int txs = (W - 2 + FT - 1) / FT, tys = (H - 2 + FT - 1) / FT;
-        const int min_tiles = getenv("HDEM_HUB_MIN_TILES") ? atoi(getenv("HDEM_HUB_MIN_TILES"))
-                                                           : HUB_MIN_TILES;
+        const int min_tiles = hub_depth ? (getenv("HDEM_HUB_MIN_TILES_NESTED")
+                                               ? atoi(getenv("HDEM_HUB_MIN_TILES_NESTED"))
+                                               : HUB_MIN_TILES_NESTED)
+                                        : (getenv("HDEM_HUB_MIN_TILES") ? atoi(getenv("HDEM_HUB_MIN_TILES"))
+                                                                        : HUB_MIN_TILES);
         if ((int64_t)txs * tys >= min_tiles) {
-            hub_ch = 2 * tys + 1;
-            hub_cw = 2 * txs + 1;
-            const size_t nt = (size_t)txs * tys, cells = (size_t)hub_ch * hub_cw;
-            const size_t need = (nt * (HUB_EDGE + 1) + 2 * cells) * sizeof(float);
-            if (ctx->hub_bytes < need) {
-                if (ctx->hub_buf) {
-                    HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-                    HDEM_HIP_CHECK(hipFree(ctx->hub_buf));
-                    ctx->hub_buf = nullptr;
-                    ctx->hub_bytes = 0;
-                }
-                if (int rc = hdem_raw_alloc(ctx, need, &ctx->hub_buf)) return rc;
-                ctx->hub_bytes = need;
-            }
-            hub_edge = (float *)ctx->hub_buf;
-            hub_node = hub_edge + nt * HUB_EDGE;
-            hub_cr = hub_node + nt;
-            hub_lev = hub_cr + cells;
+            if (int rc = hub_alloc(ctx, hub_depth, H, W, &hubs)) return rc;
+            hub_lev = hubs.lev;
         }
     }
     if (!(flags & HDEM_FILL_WARM) && eps == 0.0f && !hub_lev) {
@@ -1648,51 +1782,35 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     const int slice_us = (flags & HDEM_FILL_NO_VERIFY) ? ctx->fill_slice_us : 0;
     int64_t pending = 0;
 
-    if (hub_lev) {
+    if (hub_lev && !hub_given) {
         {
             hdem_scoped_timer tm(ctx, HDEM_K_FILL_HUB, (int64_t)H * W);
-            // (HDEM_HUB_ITERS / HDEM_HUB_WGS: experiments)
-            const int hub_iters = getenv("HDEM_HUB_ITERS") ? atoi(getenv("HDEM_HUB_ITERS")) : 3;
-            // one workgroup per tile: a resident grid of 8 per CU walking the tiles was measured
-            // at 0.77 against 0.64 ms (HDEM_HUB_WGS: that grid, per CU)
-            const int hub_grid = getenv("HDEM_HUB_WGS")
-                                     ? std::min(ws.ntiles, ctx->num_cus * atoi(getenv("HDEM_HUB_WGS")))
-                                     : ws.ntiles;
-            if (hub_iters >= 4)
-                hipLaunchKernelGGL(hub_dist_kernel<4>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
-                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
-            else if (hub_iters == 3)
-                hipLaunchKernelGGL(hub_dist_kernel<3>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
-                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
-            else if (hub_iters <= 1)
-                hipLaunchKernelGGL(hub_dist_kernel<1>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
-                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
-            else
-                hipLaunchKernelGGL(hub_dist_kernel<2>, dim3(hub_grid), dim3(NT), 0, st, z, w, H, W,
-                                   ws.tiles_x, ws.ntiles, hub_edge, hub_node);
-            hipLaunchKernelGGL(hub_edges_kernel, dim3(ws.ntiles), dim3(NT), 0, st, z, w, H, W,
-                               ws.tiles_x, ws.tiles_y, hub_edge, hub_node, hub_cr);
+            hub_launch_dist(ctx, z, w, H, W, hubs);
+            hub_launch_edges(ctx, z, w, H, W, 0, hubs);
         }
         HDEM_HIP_CHECK(hipGetLastError());
-        // the hub raster is filled by this same function (its own workspace words are set up
-        // again below: the inner call used them)
+        // the hub raster is filled by this same function (in a workspace of its own)
+        const bool was_presolve = ctx->in_coarse_presolve;
         ctx->in_coarse_presolve = true;
-        const int rc = hdem_sinkfill_f32_dev(ctx, hub_cr, hub_ch, hub_cw, 0.0f, 0,
+        ctx->hub_depth = hub_depth + 1;
+        const int rc = hdem_sinkfill_f32_dev(ctx, hubs.cr, hubs.ch, hubs.cw, 0.0f, 0,
                                              HDEM_FILL_INIT | HDEM_FILL_NO_VERIFY |
                                                  HDEM_FILL_NO_COARSE,
-                                             (float *)hub_lev, nullptr);
-        ctx->in_coarse_presolve = false;
+                                             hubs.lev, nullptr);
+        ctx->hub_depth = hub_depth;
+        ctx->in_coarse_presolve = was_presolve;
         if (rc) return rc;
-        bool no_resume = false;
-        if (int rc2 = ensure_ws(ctx, H, W, max_rounds,
-                                ctx->num_cus * std::max(1, std::min(wgs_per_cu, 16)), &no_resume, &ws))
-            return rc2;
-        ctx->fill_last_h = H;
-        ctx->fill_last_w = W;
-        ctx->fill_last_z = z;
-        ctx->fill_last_out = w;
-        ctx->fill_resumable = ctx->fill_quiescent = false;
+        if (hub_depth == 0) {                      // (the inner call wrote these for its own raster)
+            ctx->fill_last_h = H;
+            ctx->fill_last_w = W;
+            ctx->fill_last_z = z;
+            ctx->fill_last_out = w;
+            ctx->fill_resumable = ctx->fill_quiescent = false;
+        }
         // (no pass over the raster for max(d, level): every tile makes it on its first visit)
+    } else if (hub_lev) {
+        // the caller's levels: d is in w already (hdem_fill_hub_prepare_dev), the ghost rows are
+        // the caller's start values
     } else if (!warm) {
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_INIT, (int64_t)H * W);
         const size_t n = (size_t)((H + INIT_ROWS - 1) / INIT_ROWS) * ((W + 3) / 4);
@@ -1704,6 +1822,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     }
     int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
     bool have_counts = false;          // head words + counters already on the host
+    bool d8_by_stream = false;         // the certifying stream wrote the codes (every cell)
     const bool did_async = use_async && ws.ntiles > 0;
     if (did_async) {
         // ---- asynchronous phase: does (nearly) all of the work -------------------
@@ -1758,7 +1877,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // The coarse pre-solve needs no host round trip at all: whatever state its launch ends
     // in -- even one cut short -- is an upper bound of the coarse fill, which is all the
     // fine solve asks of it; its counters are only read when somebody is looking.
-    if (ctx->in_coarse_presolve && did_async && !verify && !ctx->profiling && !trace && !stats) {
+    if (ctx->in_coarse_presolve && did_async && !verify && !trace && !stats) {
         ctx->fill_resumable = ctx->fill_quiescent = false;
         return HDEM_OK;
     }
@@ -1797,7 +1916,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.error, (HEAD_INTS + stat_ints_of(ws)) * sizeof(int),
                                       hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
-        if (ctx->host_counts[4] == 0) { converged = 1; have_counts = true; }
+        if (ctx->host_counts[4] == 0) { converged = 1; have_counts = true; d8_by_stream = d8 != nullptr; }
     }
     if (ws.ntiles > 0 && verify && !converged)
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
@@ -1882,6 +2001,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         return HDEM_ERR_NOT_CONVERGED;
     }
     ctx->fill_d8_done = d8 != nullptr && converged;
+    ctx->fill_d8_ring_done = ctx->fill_d8_done && d8_by_stream;
     // the round driver leaves round stamps in the state words: no worklist to resume
     ctx->fill_resumable = did_async && !verify;
     ctx->fill_quiescent = converged != 0;
@@ -1908,8 +2028,9 @@ extern "C" int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, in
     if (rc) return rc;
     if (!ctx->fill_d8_done)              // no certifying pass over every tile: the plain kernel
         return hdem_d8_f32_dev(ctx, w, H, W, d8);
-    hipLaunchKernelGGL(d8_ring_kernel, dim3((std::max(H, W) + INIT_NT - 1) / INIT_NT),
-                       dim3(INIT_NT), 0, ctx->stream, d8, H, W);
+    if (!ctx->fill_d8_ring_done)        // (tile visits write tile interiors only)
+        hipLaunchKernelGGL(d8_ring_kernel, dim3((std::max(H, W) + INIT_NT - 1) / INIT_NT),
+                           dim3(INIT_NT), 0, ctx->stream, d8, H, W);
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }

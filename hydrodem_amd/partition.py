@@ -45,6 +45,7 @@ tests pass a NumPy solver so that this exchange logic runs under ``gloo``.
 """
 
 import contextlib
+import time
 
 import numpy as np
 
@@ -114,13 +115,18 @@ class HipLocalSolver:
         self.slice_us = slice_us
         # virtual ranks sharing one GPU (ThreadWorld) solve one at a time
         self.turn = turn
+        self.timings = []
 
     @contextlib.contextmanager
-    def _call(self):
+    def _call(self, label="call"):
         """Order the library's stream behind torch's current stream on the way in and
-        torch's behind the library's on the way out -- also when the call raises."""
+        torch's behind the library's on the way out -- also when the call raises.
+        Virtual ranks (``turn``): the call has the GPU to itself and is waited for, so its
+        wall time is what it would take on a GPU of its own -- kept in ``timings``."""
         if self.turn is not None:
             self.turn.acquire()
+            self.torch.cuda.current_stream().synchronize()
+            t0 = time.perf_counter()
         try:
             self.stream.wait_stream(self.torch.cuda.current_stream())
             try:
@@ -130,6 +136,7 @@ class HipLocalSolver:
         finally:
             if self.turn is not None:
                 self.stream.synchronize()
+                self.timings.append((label, (time.perf_counter() - t0) * 1e3))
                 self.turn.release()
 
     def _wrap(self, t, dtype):
@@ -143,7 +150,7 @@ class HipLocalSolver:
         the flow directions of the filled block (the certifying pass writes them).
         ``last_stats`` keeps the library's counters of the call."""
         sliced = bool(sliced and self.slice_us > 0)
-        with self._call():
+        with self._call("fill"):
             self.ctx.set_fill_slice_us(self.slice_us if sliced else 0)
             try:
                 if d8 is not None:
@@ -164,6 +171,26 @@ class HipLocalSolver:
         ``hdem_set_fill_coarse_start``."""
         self.ctx.set_fill_coarse_start(filled.data_ptr(), filled.shape[0], filled.shape[1],
                                        block, row_map.data_ptr())
+
+    # -- hub start of the partition (hub_start below) ---------------------------------------
+    TILE = 62                                          # tile edge of the fill (hdem_fill_stats.tile_h)
+
+    def hub_prepare(self, z, w, flags):
+        """Path costs d of every cell to its tile's hub into the interior of ``w``."""
+        with self._call("hub_prepare"):
+            self.ctx.fill_hub_prepare(z.data_ptr(), z.shape[0], z.shape[1], flags, w.data_ptr())
+
+    def hub_raster(self, z):
+        """The prepared block's hub raster (ghost rows of ``w`` hold the neighbours' d)."""
+        t = self.TILE
+        out = self.torch.empty((2 * (-(-(z.shape[0] - 2) // t)) + 1, 2 * (-(-(z.shape[1] - 2) // t)) + 1),
+                               dtype=self.torch.float32, device=z.device)
+        with self._call("hub_raster"):
+            self.ctx.fill_hub_raster(out.data_ptr())
+        return out
+
+    def set_hub_levels(self, levels):
+        self.ctx.set_fill_hub_levels(levels.data_ptr())
 
     def d8(self, w, out):
         with self._call():
@@ -423,6 +450,91 @@ def coarse_start(z_local, comm, solver, block=COARSE_BLOCK, ghost=1):
     return filled, row_map.to(torch.int32).to(z_local.device)
 
 
+HUB_BIG = 3.0e38                  # a wall of the hub raster (hdem_sinkfill.hip)
+
+
+def hub_start(z_local, w, comm, solver, flags, ghost):
+    """Start values of a partitioned fill from ONE hub graph over all blocks (epsilon = 0).
+
+    The single-GPU fill starts from a graph of tile hubs (hdem_sinkfill.hip: a hub per 62 x 62
+    tile, the minimax path cost d of every cell to its hub inside the tile, the cheapest
+    crossings between hubs of neighbouring tiles; the graph is filled exactly as a small
+    raster and a cell starts at max(d, level of its hub)).  Here every rank makes d and the
+    hub raster of its own block; the seam rows of d are swapped into the ghost rows first, so
+    that the crossings over a ghost row join a rank's top hubs to the hubs of the neighbour's
+    tiles underneath that row.  The ranks' rasters are stacked -- rank r gives its rows down to
+    the tile row that holds the row rank r+1 pins, rank r+1 continues with its crossing row --
+    all-gathered and filled by every rank (one node per tile: tiny); each rank takes its part
+    of the levels, and its ghost rows start at max(d, level) of the neighbour's tile they lie
+    in.  Returns the levels raster of the block (kept alive by the caller until the solve)."""
+    import torch
+
+    rank, world = comm.rank, comm.world
+    top, bottom = rank > 0, rank < world - 1
+    h, cols = z_local.shape
+    t = solver.TILE
+    solver.hub_prepare(z_local, w, flags)
+    # the row a neighbour pins is `ghost` rows into my block; what it gets is my d there
+    comm.swap(w[2 * ghost - 1] if top else None, w[h - 2 * ghost] if bottom else None,
+              w[0] if top else None, w[h - 1] if bottom else None)
+    d_top = w[0].clone() if top else None
+    d_bot = w[h - 1].clone() if bottom else None
+    mine = solver.hub_raster(z_local)
+    ch, cw = mine.shape
+    # my part of the stack: down to the node row of the tile that holds the row rank+1 pins
+    hi = (h - 2 * ghost - 1) // t if bottom else (ch - 1) // 2 - 1
+    keep = 2 * hi + 2 if bottom else ch
+    counts = torch.tensor([keep], dtype=torch.int64, device=z_local.device)
+    rows = torch.stack(comm.all_gather(counts)).cpu()[:, 0].tolist()
+    padded = torch.full((max(rows), cw), HUB_BIG, dtype=mine.dtype, device=mine.device)
+    padded[:keep] = mine[:keep]
+    parts = comm.all_gather(padded)
+    stack = torch.cat([p[:n] for p, n in zip(parts, rows)]).contiguous()
+    filled = torch.empty_like(stack)
+    # (the library fills a raster of this kind from a hub start of its own when it is large)
+    solver.fill(stack, filled, 0.0, backend.FILL_INIT | backend.FILL_NO_VERIFY)
+    off = [sum(rows[:r]) for r in range(world)]
+    levels = torch.full_like(mine, HUB_BIG)
+    levels[:keep] = filled[off[rank]:off[rank] + keep]
+    # the tile rows underneath my part (overlap rows that the next rank's tiles stand for in the
+    # stack): one step down the block's own crossings from the last row that has a level
+    for j in range(hi + 1, (ch - 1) // 2):
+        up = levels[2 * j - 1, 1::2]
+        up = torch.where(torch.isnan(up), torch.full_like(up, float("-inf")), up)   # an outlet above
+        node = mine[2 * j + 1, 1::2]
+        lev = torch.maximum(node, torch.maximum(up, mine[2 * j, 1::2]))
+        levels[2 * j + 1, 1::2] = torch.where(torch.isnan(node), node, lev)
+
+    def ghost_bound(d_row, lev_row, z_row):
+        # start value of a ghost row: max(d, level of the neighbour's tile the cell lies in);
+        # an outlet tile (NaN level) needs no level, nodata stays nodata, the two cells on the
+        # raster's first and last column are the raster ring
+        lev = lev_row[1::2].repeat_interleave(t)[:cols - 2]
+        lev = torch.where(lev >= HUB_BIG, torch.full_like(lev, float("inf")), lev)
+        out = d_row.clone()
+        inner = out[1:-1]
+        raised = torch.where(torch.isnan(lev) | torch.isnan(inner), inner, torch.maximum(inner, lev))
+        out[1:-1] = torch.where(raised >= HUB_BIG, torch.full_like(raised, float("inf")), raised)
+        out[0], out[-1] = z_row[0], z_row[-1]
+        return out
+
+    if top:        # my row 0 = the upper neighbour's row h' - 2 ghost, in its tile row `hi` there
+        w[0] = ghost_bound(d_top, filled[off[rank] - 1], z_local[0])
+    if bottom:     # my last row = the lower neighbour's row 2 ghost - 1
+        tj = (2 * ghost - 2) // t
+        w[h - 1] = ghost_bound(d_bot, filled[off[rank + 1] + 2 * tj + 1], z_local[h - 1])
+    solver.set_hub_levels(levels)
+    return levels
+
+
+def _block_rows(world, z_local, comm, ghost):
+    """Rows of every rank's local array (the hub start wants blocks that hold the rows their
+    neighbours pin well inside a tile row of their own)."""
+    import torch
+    mine = torch.tensor([z_local.shape[0]], dtype=torch.int64, device=z_local.device)
+    return torch.stack(comm.all_gather(mine)).cpu()[:, 0].tolist()
+
+
 def _comm_for(rank, world, group, comm):
     if comm is None:
         comm = DistComm(group)
@@ -434,7 +546,7 @@ def _comm_for(rank, world, group, comm):
 
 def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
                          max_exchanges=100000, group=None, coarse_block=None, d8_out=None,
-                         ghost=1, comm=None):
+                         ghost=1, comm=None, hub=True):
     """Sink fill of a row-block partitioned raster.
 
     ``z_local``: torch tensor, local rows incl. ghost rows (see
@@ -467,7 +579,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
         # 8192 x 1024 cells and 1.6 ms, and 32 x 32 blocks would cost more in the fine
         # solve than they save here: 16.1 against 15.4 ms predicted)
         coarse_block = COARSE_BLOCK
-    tally = {"tile_visits": 0, "unchanged": 0, "solves": [], "fallbacks": 0, "shared": 0}
+    tally = {"tile_visits": 0, "unchanged": 0, "solves": [], "fallbacks": 0, "shared": 0,
+             "start": "inf"}
 
     def solve(phase, fill_flags, **kw):
         v, lowered, pending = solver.fill(z_local, w, eps, fill_flags, **kw)
@@ -482,9 +595,15 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     keep = None
     if world > 1:
         comm = _comm_for(rank, world, group, comm)
-        if eps == 0.0 and coarse_block:
+        if eps == 0.0 and hub and hasattr(solver, "hub_prepare") and \
+                all(n >= 4 * ghost + 2 * 62 for n in _block_rows(world, z_local, comm, ghost)):
+            keep = hub_start(z_local, w, comm, solver, flags, ghost)
+            flags |= backend.FILL_GHOST_GIVEN
+            tally["start"] = "hub"
+        elif eps == 0.0 and coarse_block:
             keep = coarse_start(z_local, comm, solver, coarse_block, ghost)
             solver.set_coarse_start(keep[0], coarse_block, keep[1])
+            tally["start"] = "blockmax"
     _, pending = solve("first", flags | backend.FILL_NO_VERIFY, sliced=sliced)
     del keep                                       # (alive until the solve has consumed them)
     exchanges = verifications = 0
@@ -516,7 +635,7 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     return w, {"tile_visits": tally["tile_visits"], "visits_unchanged": tally["unchanged"],
                "exchanges": exchanges, "verifications": verifications,
                "solves": tally["solves"], "async_fallbacks": tally["fallbacks"],
-               "shared_gpu_solves": tally["shared"]}
+               "shared_gpu_solves": tally["shared"], "start_values": tally["start"]}
 
 
 def d8_distributed(w_local, solver, out=None):

@@ -198,6 +198,26 @@ int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float 
  * HDEM_FILL_WARM | HDEM_FILL_RESUME.  This is what lets row blocks on different
  * GPUs trade ghost rows every millisecond instead of once per local convergence. */
 int hdem_set_fill_slice_us(hdem_ctx *ctx, int microseconds);
+
+/* Hub start of a row-block partition (new work; no reference counterpart -- SURVEY 8e).  The
+ * single-GPU fill starts from a graph of tile hubs (one hub per 62 x 62 tile, path costs d to
+ * it inside the tile, cheapest crossings between hubs of neighbouring tiles, the graph filled
+ * exactly as a small raster: hdem_sinkfill.hip).  A partition builds ONE such graph:
+ *   hdem_fill_hub_prepare_dev   d of this block into the interior of w (flags: GHOST_TOP /
+ *                               GHOST_BOTTOM as for the fill); the caller then puts the rows of
+ *                               the neighbours' d that are its ghost rows into w's ghost rows;
+ *   hdem_fill_hub_raster_dev    this block's hub raster, (2 ty + 1) x (2 tx + 1) floats with
+ *                               ty x tx = ceil((H - 2) / 62) x ceil((W - 2) / 62) tiles: hubs at
+ *                               odd/odd, crossings between them; the first (last) row holds the
+ *                               crossings to the raster's first (last) row, or -- ghost row -- to
+ *                               the neighbouring block's hubs;
+ *   hdem_set_fill_hub_levels    the filled levels of this block's part of the stacked raster
+ *                               (same shape), for the next INIT fill of the same z / w: that fill
+ *                               skips its own start-value work; with GHOST_GIVEN the ghost rows
+ *                               of w are the caller's upper bounds.  Used once. */
+int hdem_fill_hub_prepare_dev(hdem_ctx *ctx, const float *z, int H, int W, int flags, float *w);
+int hdem_fill_hub_raster_dev(hdem_ctx *ctx, float *raster);
+int hdem_set_fill_hub_levels(hdem_ctx *ctx, const float *levels);
 /* Start values for the NEXT hdem_sinkfill_f32_dev INIT call with eps = 0 on this context:
  * coarse_filled is the sink fill of a block-maximum raster (hdem_blockmax_f32_dev) that
  * covers this raster -- ch x cw floats on the device, block a power of two in 4..256;
