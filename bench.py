@@ -120,7 +120,10 @@ def launch_ranks(n):
                 p.kill()
     if failed is not None:
         raise SystemExit(f"bench.py: rank {failed[0]} exited with status {failed[1]}")
-    sys.stdout.write(line.decode())
+    # (only the record: gloo announces its connections on stdout in the rehearsal)
+    for text in line.decode().splitlines():
+        if text.startswith('{"metric"'):
+            sys.stdout.write(text + "\n")
     sys.stdout.flush()
 
 

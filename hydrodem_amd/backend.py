@@ -101,11 +101,13 @@ SIGNATURES = {
     "hdem_isolated_points_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_expand_u8_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_fft2_c2c_f32_dev": [_vp, _vp, _i, _i, _i],
+    "hdem_fft2_c2c_f64_dev": [_vp, _vp, _i, _i, _i],
     "hdem_correct_nan_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_majority_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_binary_erosion_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp],
     "hdem_binary_closing_u8_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "hdem_grey_dilation_f32_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "hdem_grey_dilation_f64_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
     "hdem_tidying_lagoons_f32_dev": [_vp, _vp, _i, _i, _vp],
     "hdem_lagoons_detection_f32_dev": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "hdem_sinkfill_d8_f32_dev": [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp,
@@ -115,6 +117,7 @@ SIGNATURES = {
     "hdem_boxmean3_f32_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_boxmean3_f64_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_convolve_f32": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "hdem_convolve_f64": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "hdem_around_f32": [_vp, _vp, _c.c_int64, _vp],
     "hdem_around_f64": [_vp, _vp, _c.c_int64, _vp],
     "hdem_quadratic_f32": [_vp, _vp, _i, _i, _i, _vp],
@@ -292,7 +295,7 @@ def device_count():
 
 
 _DTYPES = {np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.uint8),
-           np.dtype(np.complex64), np.dtype(np.int64)}
+           np.dtype(np.complex64), np.dtype(np.complex128), np.dtype(np.int64)}
 
 
 class _HostBlocks:
@@ -305,8 +308,12 @@ class _HostBlocks:
     bus together for every operator here.  Results of 32 MiB and more are therefore NumPy
     arrays over page-locked blocks that return here when the array (and every view of it)
     has gone, and are handed out again for the next result of that size.  The cache is capped
-    (``HDEM_HOST_POOL_MIB``, default 8 GiB; 0 = plain ``np.empty``); blocks beyond it are
-    unlocked and freed at once."""
+    (``HDEM_HOST_POOL_MIB``, default 8 GiB; 0 = plain ``np.empty``), and so is what may be
+    page-locked at any one time, arrays in the caller's hands included
+    (``HDEM_HOST_PINNED_MAX_MIB``, default 4 x the cache): beyond it results are plain
+    ``np.empty`` arrays.  A block the cache has no room for is unlocked by the next call that
+    asks for memory here, not by the finalizer that returned it -- that one runs on whatever
+    thread drops the last reference and makes no device call."""
 
     MIN_BYTES = 32 << 20
 
@@ -314,8 +321,12 @@ class _HostBlocks:
         self.lock = threading.Lock()
         self.spare = {}                      # nbytes -> [address, ...]
         self.cached = 0
+        self.outstanding = 0                 # page-locked bytes in callers' hands
+        self.to_free = []                    # blocks waiting to be unlocked
         mib = os.environ.get("HDEM_HOST_POOL_MIB")
         self.cap = (int(mib) << 20) if mib is not None else (8 << 30)
+        mib = os.environ.get("HDEM_HOST_PINNED_MAX_MIB")
+        self.pinned_max = (int(mib) << 20) if mib is not None else 4 * self.cap
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -326,13 +337,24 @@ class _HostBlocks:
         try:
             ctx = context()
             with self.lock:
+                doomed, self.to_free = self.to_free, []
                 stack = self.spare.get(nbytes)
                 addr = stack.pop() if stack else None
                 if addr is not None:
                     self.cached -= nbytes
+                elif self.outstanding + self.cached + nbytes > self.pinned_max:
+                    addr = 0                     # enough is page-locked already
+                if addr != 0:
+                    self.outstanding += nbytes
+            for old in doomed:
+                ctx.lib.hdem_host_free(ctx.handle, ctypes.c_void_p(old))
+            if addr == 0:
+                return np.empty(shape, dtype)
             if addr is None:
                 ptr = ctypes.c_void_p()
                 if ctx.lib.hdem_host_alloc(ctx.handle, nbytes, ctypes.byref(ptr)) != 0 or not ptr.value:
+                    with self.lock:
+                        self.outstanding -= nbytes
                     return np.empty(shape, dtype)
                 addr = ptr.value
             buf = (ctypes.c_char * nbytes).from_address(addr)
@@ -343,16 +365,14 @@ class _HostBlocks:
             return np.empty(shape, dtype)
 
     def _give_back(self, addr, nbytes):
-        try:
-            with self.lock:
-                if self.cached + nbytes <= self.cap:
-                    self.spare.setdefault(nbytes, []).append(addr)
-                    self.cached += nbytes
-                    return
-            ctx = context()
-            ctx.lib.hdem_host_free(ctx.handle, ctypes.c_void_p(addr))
-        except Exception:  # pylint: disable=broad-except
-            pass                                 # (interpreter shutdown: the process is going)
+        # (a finalizer: any thread, possibly during interpreter shutdown -- no device call)
+        with self.lock:
+            self.outstanding -= nbytes
+            if self.cached + nbytes <= self.cap:
+                self.spare.setdefault(nbytes, []).append(addr)
+                self.cached += nbytes
+            else:
+                self.to_free.append(addr)
 
 
 _host_blocks = _HostBlocks()
@@ -570,11 +590,15 @@ def expand_dev(mask, window_size=13, out=None):
 
 
 def fft2_dev(data, inverse=False):
-    """In-place 2-D complex64 transform; the inverse is unnormalised."""
-    _need(data, np.complex64)
+    """In-place 2-D transform of a complex64 or complex128 raster; the inverse is
+    unnormalised."""
     c = data.ctx
-    c.check(c.lib.hdem_fft2_c2c_f32_dev(c.handle, data.ptr, data.shape[0], data.shape[1],
-                                        int(bool(inverse))))
+    if data.dtype == np.complex128:
+        fn = c.lib.hdem_fft2_c2c_f64_dev
+    else:
+        _need(data, np.complex64)
+        fn = c.lib.hdem_fft2_c2c_f32_dev
+    c.check(fn(c.handle, data.ptr, data.shape[0], data.shape[1], int(bool(inverse))))
     return data
 
 
@@ -656,12 +680,16 @@ def binary_closing_dev(mask, structure=None, out=None):
 
 
 def grey_dilation_dev(img, size, out=None):
-    _need(img, np.float32)
+    """float32 or float64 raster; the result has the input's type."""
     c = img.ctx
-    out = out or DeviceRaster.empty(img.shape, np.float32, c)
+    if img.dtype == np.float64:
+        fn = c.lib.hdem_grey_dilation_f64_dev
+    else:
+        _need(img, np.float32)
+        fn = c.lib.hdem_grey_dilation_f32_dev
+    out = out or DeviceRaster.empty(img.shape, img.dtype, c)
     sy, sx = (size, size) if np.isscalar(size) else size
-    c.check(c.lib.hdem_grey_dilation_f32_dev(c.handle, img.ptr, img.shape[0], img.shape[1],
-                                             int(sy), int(sx), out.ptr))
+    c.check(fn(c.handle, img.ptr, img.shape[0], img.shape[1], int(sy), int(sx), out.ptr))
     return out
 
 
@@ -798,13 +826,17 @@ def boxmean3(x, do_round=True):
 
 
 def convolve(x, weights):
+    """General odd weights: float32 rasters in float32, anything else in float64 -- the
+    type scipy.ndimage.convolve works in for a float64 raster (extension_filters.py:183)."""
     c = context()
-    x = _host2d(x, np.float32)
+    if np.asarray(x).dtype == np.float32:
+        x, fn = _host2d(x, np.float32), c.lib.hdem_convolve_f32
+    else:
+        x, fn = _host2d(x, np.float64), c.lib.hdem_convolve_f64
     w = _host2d(weights, np.float64)
     out = host_empty(x.shape, x.dtype)
-    c.check(c.lib.hdem_convolve_f32(c.handle, x.ctypes.data, x.shape[0], x.shape[1],
-                                    w.ctypes.data, w.shape[0], w.shape[1],
-                                    out.ctypes.data))
+    c.check(fn(c.handle, x.ctypes.data, x.shape[0], x.shape[1], w.ctypes.data, w.shape[0],
+               w.shape[1], out.ctypes.data))
     return out
 
 
@@ -866,10 +898,14 @@ def expand(mask, window_size=13, dtype=np.uint8):
 
 
 def fft2(x, inverse=False):
-    """fft2 / ifft2 (normalised) of a 2-D array in complex64."""
-    a = _host2d(x, np.complex64)
+    """fft2 / ifft2 (normalised) of a 2-D array: complex64 for float32 / complex64 input,
+    complex128 for anything else -- scipy.fftpack's rule (extension_filters.py:379,414)."""
+    single = np.asarray(x).dtype in (np.dtype(np.float32), np.dtype(np.complex64))
+    a = _host2d(x, np.complex64 if single else np.complex128)
     d = fft2_dev(DeviceRaster.from_host(a), inverse).to_host()
-    return d / np.float32(a.size) if inverse else d
+    if not inverse:
+        return d
+    return d / (np.float32(a.size) if single else np.float64(a.size))
 
 
 def mask_bytes(groves_class):

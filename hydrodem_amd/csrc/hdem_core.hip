@@ -292,7 +292,7 @@ extern "C" int hdem_free(hdem_ctx *ctx, void *dptr)
 // A device-to-host copy into memory the process has never touched (a fresh np.empty) runs
 // at 10-17 GB/s instead of 56: the copy engine's staging path takes the page faults one by
 // one.  Taking them first, on many threads, costs a few milliseconds per GiB -- the whole
-// destination range is about to be overwritten, so writing one byte per page is harmless.
+// destination range is about to be overwritten; one byte per page is rewritten with itself.
 static void prefault_host(void *dst, size_t bytes)
 {
     constexpr size_t PAGE = 4096, MIN_BYTES = (size_t)32 << 20;
@@ -315,9 +315,11 @@ static void prefault_host(void *dst, size_t bytes)
             const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
             if (lo >= hi) break;
             pool.emplace_back([base, lo, hi] {
-                for (size_t o = lo; o < hi; o += PAGE)
-                    *reinterpret_cast<volatile char *>(base + o) = 0;
-                *reinterpret_cast<volatile char *>(base + hi - 1) = 0;
+                // (each byte written back as it was: the destination may be an array the caller
+                // still reads if the copy fails, e.g. an in-place repair of its input)
+                auto touch = [](volatile char *p) { const char c = *p; *p = c; };
+                for (size_t o = lo; o < hi; o += PAGE) touch(base + o);
+                touch(base + hi - 1);
             });
         }
     } catch (...) {

@@ -38,7 +38,7 @@ typedef struct rocfft_plan_description_t *rocfft_plan_description;
 enum { ROCFFT_COMPLEX_FORWARD = 0, ROCFFT_COMPLEX_INVERSE = 1, ROCFFT_REAL_FORWARD = 2 };
 enum { ROCFFT_INPLACE = 0, ROCFFT_NOTINPLACE = 1 };
 enum { ROCFFT_ARRAY_REAL = 2, ROCFFT_ARRAY_HERMITIAN_INTERLEAVED = 3 };
-enum { ROCFFT_SINGLE = 0 };
+enum { ROCFFT_SINGLE = 0, ROCFFT_DOUBLE = 1 };
 
 struct rocfft_api {
     void *handle = nullptr;
@@ -873,6 +873,44 @@ extern "C" int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, i
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     if (int rc = ensure_plans(ctx, H, W)) return rc;
     return run_fft(ctx, inverse != 0, (float2 *)data);
+}
+
+// The same transform in double precision, for float64 / complex128 input -- what
+// scipy.fftpack.fft2 / ifft2 compute for it (extension_filters.py:379,414).  A standalone
+// operator off the pipeline's path (the pipeline transforms float32 rasters): plan and work
+// buffer are made for the call and released behind it.
+extern "C" int hdem_fft2_c2c_f64_dev(hdem_ctx *ctx, double *data, int H, int W, int inverse)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    if (int rc = hdem_check_raster(data, data, H, W)) return rc;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    if (int rc = load_rocfft()) return rc;
+    const size_t lengths[2] = {(size_t)W, (size_t)H};
+    rocfft_plan plan = nullptr;
+    HDEM_REQUIRE(g_fft.plan_create(&plan, ROCFFT_INPLACE,
+                                   inverse ? ROCFFT_COMPLEX_INVERSE : ROCFFT_COMPLEX_FORWARD,
+                                   ROCFFT_DOUBLE, 2, lengths, 1, nullptr) == 0,
+                 HDEM_ERR_HIP, "rocfft_plan_create (double, %d x %d) failed", H, W);
+    size_t work_bytes = 0;
+    g_fft.plan_get_work_buffer_size(plan, &work_bytes);
+    rocfft_execution_info info = nullptr;
+    hdem_dbuf work;
+    int rc = HDEM_OK;
+    if (g_fft.info_create(&info) != 0) rc = HDEM_ERR_HIP;
+    if (!rc && work_bytes) rc = work.alloc(ctx, work_bytes);
+    if (!rc && work_bytes && g_fft.info_set_work_buffer(info, work.p, work_bytes) != 0) rc = HDEM_ERR_HIP;
+    if (!rc && g_fft.info_set_stream(info, ctx->stream) != 0) rc = HDEM_ERR_HIP;
+    if (!rc) {
+        void *in[1] = {data};
+        hdem_scoped_timer tm(ctx, HDEM_K_FFT, (int64_t)H * W);
+        if (g_fft.execute(plan, in, nullptr, info) != 0) rc = HDEM_ERR_HIP;
+    }
+    // (the plan's kernels are on the stream; the plan and its work buffer go behind them)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = HDEM_ERR_HIP;
+    if (info) g_fft.info_destroy(info);
+    g_fft.plan_destroy(plan);
+    if (rc == HDEM_ERR_HIP) hdem_set_error("rocFFT double-precision transform (%d x %d) failed", H, W);
+    return rc;
 }
 
 extern "C" int hdem_fourier_destripe_f32_dev(hdem_ctx *ctx, const float *dem, int H, int W,

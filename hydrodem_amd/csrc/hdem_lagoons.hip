@@ -381,22 +381,23 @@ __device__ __forceinline__ int reflect(int i, int n)
 // compile time (7 x 7 is the only size the reference uses), 0: run-time sizes.
 constexpr int GTX = 64, GTY = 32;
 
-template <int CSY, int CSX>
-__global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restrict__ in, int h,
+template <int CSY, int CSX, typename T>
+__global__ __launch_bounds__(NT) void grey_dilation_kernel(const T *__restrict__ in, int h,
                                                            int w, int sy_, int sx_,
-                                                           float *__restrict__ out)
+                                                           T *__restrict__ out)
 {
-    extern __shared__ float tile[];
+    extern __shared__ __attribute__((aligned(8))) unsigned char tile_bytes[];
+    T *tile = reinterpret_cast<T *>(tile_bytes);
     const int sy = CSY ? CSY : sy_, sx = CSX ? CSX : sx_;
     const int ry = sy / 2, rx = sx / 2, tw = GTX + 2 * rx, th = GTY + 2 * ry;
-    float *rowmax = tile + tw * th;                 // th x GTX
+    T *rowmax = tile + tw * th;                     // th x GTX
     const int x0 = blockIdx.x * GTX, y0 = blockIdx.y * GTY;
     if (CSY && CSX) {
         // compiled-in size: all loads of the thread in flight together (a load -> ds_write
         // loop waits out one memory round trip per cell: 0.78 against 0.50 ms at 16384^2)
         constexpr int CELLS = (GTX + (CSX ? CSX : 1) - 1) * (GTY + (CSY ? CSY : 1) - 1);
         constexpr int LOADS = (CELLS + NT - 1) / NT;
-        float v[LOADS];
+        T v[LOADS];
 #pragma unroll
         for (int j = 0; j < LOADS; ++j) {
             const int k = min((int)threadIdx.x + j * NT, CELLS - 1), ly = k / tw, lx = k - ly * tw;
@@ -414,10 +415,10 @@ __global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restri
     __syncthreads();
     const int lx = threadIdx.x % GTX;
     for (int ly = threadIdx.x / GTX; ly < th; ly += NT / GTX) {
-        float m = -__builtin_inff();
+        T m = -(T)__builtin_inff();
 #pragma unroll
         for (int dx = 0; dx < sx; ++dx) {
-            const float v = tile[ly * tw + lx + dx];
+            const T v = tile[ly * tw + lx + dx];
             m = v > m ? v : m;
         }
         rowmax[ly * GTX + lx] = m;
@@ -426,10 +427,10 @@ __global__ __launch_bounds__(NT) void grey_dilation_kernel(const float *__restri
     for (int ly = threadIdx.x / GTX; ly < GTY; ly += NT / GTX) {
         const int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
-        float m = tile[(ly + ry) * tw + lx + rx];
+        T m = tile[(ly + ry) * tw + lx + rx];
 #pragma unroll
         for (int dy = 0; dy < sy; ++dy) {
-            const float v = rowmax[(ly + dy) * GTX + lx];
+            const T v = rowmax[(ly + dy) * GTX + lx];
             m = v > m ? v : m;
         }
         out[(size_t)y * w + x] = m;
@@ -718,8 +719,8 @@ extern "C" int hdem_binary_closing_u8_dev(hdem_ctx *ctx, const uint8_t *mask, in
     return HDEM_OK;
 }
 
-extern "C" int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int sy,
-                                          int sx, float *out)
+template <typename T>
+static int grey_dilation_dev(hdem_ctx *ctx, const T *img, int H, int W, int sy, int sx, T *out)
 {
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
     if (int rc = hdem_check_raster(img, out, H, W)) return rc;
@@ -730,17 +731,26 @@ extern "C" int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H
     {
         hdem_scoped_timer tm(ctx, HDEM_K_LAGOON, (int64_t)H * W);
         const dim3 grid((W + GTX - 1) / GTX, (H + GTY - 1) / GTY);
-        const size_t lds = (size_t)(GTX + sx - 1 + GTX) * (GTY + sy - 1) * sizeof(float);
+        const size_t lds = (size_t)(GTX + sx - 1 + GTX) * (GTY + sy - 1) * sizeof(T);
         if (sy == 7 && sx == 7)
-            hipLaunchKernelGGL((grey_dilation_kernel<7, 7>), grid, dim3(NT), lds, ctx->stream, img,
+            hipLaunchKernelGGL((grey_dilation_kernel<7, 7, T>), grid, dim3(NT), lds, ctx->stream, img,
                                H, W, sy, sx, out);
         else
-            hipLaunchKernelGGL((grey_dilation_kernel<0, 0>), grid, dim3(NT), lds, ctx->stream, img,
+            hipLaunchKernelGGL((grey_dilation_kernel<0, 0, T>), grid, dim3(NT), lds, ctx->stream, img,
                                H, W, sy, sx, out);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     return HDEM_OK;
 }
+
+extern "C" int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int sy,
+                                          int sx, float *out)
+{ return grey_dilation_dev<float>(ctx, img, H, W, sy, sx, out); }
+// (float64 rasters keep their values: scipy.ndimage.grey_dilation works in the input's type,
+// extension_filters.py:345)
+extern "C" int hdem_grey_dilation_f64_dev(hdem_ctx *ctx, const double *img, int H, int W, int sy,
+                                          int sx, double *out)
+{ return grey_dilation_dev<double>(ctx, img, H, W, sy, sx, out); }
 
 static size_t round16(size_t n) { return (n + 15) / 16 * 16; }
 

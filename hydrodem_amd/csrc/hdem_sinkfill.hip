@@ -47,6 +47,7 @@
 #include "hdem_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -1125,8 +1126,10 @@ __global__ __launch_bounds__(NT) void hub_edges_kernel(const float *__restrict__
         const int xx = x0 + lane;
         if (xx > W - 1) return HDEM_INF;
         if (ghost) {
-            const float v = wg[(size_t)yr * W + xx];
-            return (lane == 0 || lane == WN - 1) ? HDEM_INF : fminf(v, HDEM_INF);
+            // (nor do its two end cells, raster ring: a crossing to them is an outlet of MY
+            // tile, and this crossing stands for both hubs it joins)
+            const bool out = lane == 0 || lane == WN - 1 || xx == 0 || xx == W - 1;
+            return out ? HDEM_INF : fminf(wg[(size_t)yr * W + xx], HDEM_INF);
         }
         const float v = zg[(size_t)yr * W + xx];
         wg[(size_t)yr * W + xx] = v;
@@ -1318,7 +1321,8 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
                                                       int ghost_given,
                                                       const float *__restrict__ coarse, int cw,
                                                       int shift,
-                                                      const int *__restrict__ row_map)
+                                                      const int *__restrict__ row_map,
+                                                      float level_add)
 {
     // A lane makes 4 columns x INIT_ROWS rows: INIT_ROWS + 2 rows of loads (all in flight
     // together) instead of 3 per output row.
@@ -1352,7 +1356,9 @@ __global__ __launch_bounds__(INIT_NT) void fill_init_kernel(const float *__restr
         float level = HDEM_INF;
         if (coarse) {
             level = coarse[(size_t)(row_map ? row_map[y] : (y >> shift)) * cw + (x >> shift)];
-            if (level >= 3.0e38f) level = HDEM_INF;            // a nodata wall stays a wall
+            // a nodata wall stays a wall; with a gradient the block's level is only reached
+            // after up to a block's width of steps (level_add, see the host side)
+            level = level >= 3.0e38f ? HDEM_INF : level + level_add;
         }
         float o[4];
 #pragma unroll
@@ -1523,6 +1529,21 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     HDEM_HIP_CHECK(hipMemsetAsync(sevens, 0x7f, (size_t)(ws->zmax + n - sevens) * sizeof(int),
                                   ctx->stream));
     return HDEM_OK;
+}
+
+// largest |value| among the cells that are not walls (gradient fill: the rounding allowance of
+// its coarse start is a multiple of the ulp up there).  Non-negative floats order like ints.
+__global__ __launch_bounds__(INIT_NT) void absmax_kernel(const float *__restrict__ v, size_t n,
+                                                         int *__restrict__ out)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * INIT_NT + threadIdx.x; i < n; i += (size_t)gridDim.x * INIT_NT) {
+        const float a = fabsf(v[i]);
+        if (a < HUB_BIG) m = fmaxf(m, a);          // (NaN compares false)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(int, m));
 }
 
 struct hub_bufs {
@@ -1712,7 +1733,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             hub_lev = hubs.lev;
         }
     }
-    if (!(flags & HDEM_FILL_WARM) && eps == 0.0f && !hub_lev) {
+    float coarse_add = 0.0f;
+    if (!(flags & HDEM_FILL_WARM) && !hub_lev && (eps == 0.0f || !ctx->start_coarse)) {
         if (ctx->start_coarse) {
             coarse = ctx->start_coarse;
             row_map = ctx->start_row_map;
@@ -1727,7 +1749,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             // it bounds the fine fill of its block from above
             const int cshift = getenv("HDEM_COARSE_SHIFT") ? atoi(getenv("HDEM_COARSE_SHIFT")) : COARSE_SHIFT;
             const int b = 1 << cshift, ch = (H + b - 1) / b, cwid = (W + b - 1) / b;
-            const size_t need = (size_t)2 * ch * cwid * sizeof(float);
+            const size_t need = ((size_t)2 * ch * cwid + 4) * sizeof(float);
             if (ctx->coarse_bytes < need) {
                 if (ctx->coarse_buf) {
                     HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1740,8 +1762,32 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             }
             float *cz = (float *)ctx->coarse_buf, *cfill = cz + (size_t)ch * cwid;
             if (int rc = hdem_blockmax_f32_dev(ctx, z, H, W, b, cz)) return rc;
+            float coarse_eps = 0.0f;
+            if (eps != 0.0f) {
+                // Gradient fill (eps > 0): a fine path that follows a chain of blocks makes at
+                // most b steps per block of the chain, every step adds eps -- in float32: at
+                // most eps + half an ulp of the value, and every value of the fill is below
+                // twice the largest |elevation| + what the path adds -- so the coarse raster
+                // filled with  eps_c = b (eps + ulp) + ulp  (the last ulp: its own additions
+                // round too) bounds a cell of block B by  level(B) + b (eps + ulp) + 2 ulp:
+                // up to b steps from the cell to the chain, one rounding of that sum.
+                int *amax = (int *)(cfill + (size_t)ch * cwid);
+                HDEM_HIP_CHECK(hipMemsetAsync(amax, 0, sizeof(int), ctx->stream));
+                hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(INIT_NT), 0, ctx->stream, cz,
+                                   (size_t)ch * cwid, amax);
+                float top = 0.0f;
+                HDEM_HIP_CHECK(hipMemcpyAsync(&top, amax, sizeof(float), hipMemcpyDeviceToHost,
+                                              ctx->stream));
+                HDEM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                // (values may climb above the highest block by the gradient itself: twice the
+                // top, and never less than 1, is a generous binade)
+                const float span = 2.0f * std::max(top, 1.0f) + (float)(ch + cwid) * b * eps;
+                const float ulp = std::nextafter(span, HDEM_INF) - span;
+                coarse_eps = (float)b * (eps + ulp) + ulp;
+                coarse_add = (float)b * (eps + ulp) + 2.0f * ulp;
+            }
             ctx->in_coarse_presolve = true;
-            const int rc = hdem_sinkfill_f32_dev(ctx, cz, ch, cwid, 0.0f, 0,
+            const int rc = hdem_sinkfill_f32_dev(ctx, cz, ch, cwid, coarse_eps, 0,
                                                  HDEM_FILL_INIT | HDEM_FILL_NO_VERIFY |
                                                      HDEM_FILL_NO_COARSE,
                                                  cfill, nullptr);
@@ -1818,7 +1864,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
                            dim3(INIT_NT), 0, st, z, w, H, W, ws.tiles_x, ws.tile_key,
                            flags & HDEM_FILL_GHOST_TOP, flags & HDEM_FILL_GHOST_BOTTOM,
                            flags & HDEM_FILL_GHOST_GIVEN, coarse, coarse_cw, coarse_shift,
-                           row_map);
+                           row_map, coarse_add);
     }
     int converged = ws.ntiles == 0 ? 1 : 0, round = 0, async_error = 0;
     bool have_counts = false;          // head words + counters already on the host

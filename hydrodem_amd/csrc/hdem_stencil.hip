@@ -322,9 +322,10 @@ __global__ __launch_bounds__(NT) void boxmean3_kernel(const T *__restrict__ x, i
 // one thread per cell, L2-served re-reads -- this is the generic path, the
 // 3x3 ones() default takes boxmean3_kernel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void convolve_kernel(const float *__restrict__ x, int H,
+template <typename T>
+__global__ __launch_bounds__(NT) void convolve_kernel(const T *__restrict__ x, int H,
                                                      int W, const double *__restrict__ wt,
-                                                     int kh, int kw, float *__restrict__ out)
+                                                     int kh, int kw, T *__restrict__ out)
 {
     size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
     if (i >= (size_t)H * W) return;
@@ -339,8 +340,10 @@ __global__ __launch_bounds__(NT) void convolve_kernel(const float *__restrict__ 
                 acc += (double)x[(size_t)gy * W + reflect(xx + k - px, W)] * w;
         }
     }
-    float s = (float)acc;
-    out[i] = s / (float)(kh * kw);
+    // SciPy writes the double sum in the array's type; the reference then divides by
+    // weights.size in that type (extension_filters.py:183)
+    const T s = (T)acc;
+    out[i] = s / (T)(kh * kw);
 }
 
 template <typename T>
@@ -451,8 +454,9 @@ extern "C" int hdem_boxmean3_f32(hdem_ctx *c, const float *x, int H, int W, int 
 extern "C" int hdem_boxmean3_f64(hdem_ctx *c, const double *x, int H, int W, int r, double *o)
 { return boxmean_host<double>(c, x, H, W, r, o); }
 
-extern "C" int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
-                                 const double *weights, int kh, int kw, float *out)
+template <typename T>
+static int convolve_host(hdem_ctx *ctx, const T *x, int H, int W, const double *weights, int kh,
+                         int kw, T *out)
 {
     HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
     if (int rc = hdem_check_raster(x, out, H, W)) return rc;
@@ -464,20 +468,29 @@ extern "C" int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
     HDEM_HIP_CHECK(hipSetDevice(ctx->device));
     size_t n = (size_t)H * W;
     hdem_dbuf dx, dout, dw;
-    if (int rc = dx.alloc(ctx, n * sizeof(float))) return rc;
-    if (int rc = dout.alloc(ctx, n * sizeof(float))) return rc;
+    if (int rc = dx.alloc(ctx, n * sizeof(T))) return rc;
+    if (int rc = dout.alloc(ctx, n * sizeof(T))) return rc;
     if (int rc = dw.alloc(ctx, sizeof(double) * kh * kw)) return rc;
-    if (int rc = hdem_memcpy_h2d(ctx, dx.p, x, n * sizeof(float))) return rc;
+    if (int rc = hdem_memcpy_h2d(ctx, dx.p, x, n * sizeof(T))) return rc;
     if (int rc = hdem_memcpy_h2d(ctx, dw.p, weights, sizeof(double) * kh * kw)) return rc;
     {
         hdem_scoped_timer tm(ctx, HDEM_K_CONVOLVE, (int64_t)n);
-        hipLaunchKernelGGL(convolve_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
-                           ctx->stream, (const float *)dx.p, H, W, (const double *)dw.p, kh,
-                           kw, (float *)dout.p);
+        hipLaunchKernelGGL(convolve_kernel<T>, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
+                           ctx->stream, (const T *)dx.p, H, W, (const double *)dw.p, kh, kw,
+                           (T *)dout.p);
     }
     HDEM_HIP_CHECK(hipGetLastError());
-    return hdem_memcpy_d2h(ctx, out, dout.p, n * sizeof(float));
+    return hdem_memcpy_d2h(ctx, out, dout.p, n * sizeof(T));
 }
+
+extern "C" int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
+                                 const double *weights, int kh, int kw, float *out)
+{ return convolve_host<float>(ctx, x, H, W, weights, kh, kw, out); }
+// (a float64 raster is convolved in float64, as scipy.ndimage.convolve does:
+// extension_filters.py:183)
+extern "C" int hdem_convolve_f64(hdem_ctx *ctx, const double *x, int H, int W,
+                                 const double *weights, int kh, int kw, double *out)
+{ return convolve_host<double>(ctx, x, H, W, weights, kh, kw, out); }
 
 template <typename T>
 static int around_host(hdem_ctx *ctx, const T *x, int64_t n, T *out)

@@ -68,9 +68,37 @@ class LazyResults(dict):
     def keys(self):
         return list(dict.fromkeys(list(dict.keys(self)) + list(self.device)))
 
-    def release(self):
-        """Free the device copies (host copies already made stay)."""
+    # every other read goes through keys() / __getitem__ as well, so that a stage that is
+    # still only on the device is there for get(), iteration, items(), values() and len()
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def downloaded(self):
+        """Names of the stages that have a host copy already."""
+        return list(dict.keys(self))
+
+    def release(self, keep=None):
+        """Free the device copies (host copies already made stay).  A raster stored under
+        two names -- a member whose ``apply_device`` hands its input on -- is freed once;
+        ``keep``: a raster the caller goes on using (the last stage ``apply_device``
+        returned) is left alone."""
+        seen = set()
         for raster in self.device.values():
+            if raster is keep or id(raster) in seen:
+                continue
+            seen.add(id(raster))
             raster.free()
         self.device = {}
 

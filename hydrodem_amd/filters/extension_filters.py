@@ -41,8 +41,8 @@ class Convolve(Filter):  # pylint: disable=too-few-public-methods
     input dtype (extension_filters.py:133-184).
 
     The default ``ones((3, 3))`` takes the LDS-tiled 3x3 kernel (float32 and
-    float64); other odd weights up to 15 x 15 take the general kernel, which
-    computes in float32 storage.
+    float64); other odd weights up to 15 x 15 take the general kernel (float32
+    rasters in float32, everything else in float64, as SciPy does).
     """
 
     auto_device = True      # device form == host form for a float32 raster
@@ -152,17 +152,18 @@ class BinaryClosing(Filter):  # pylint: disable=too-few-public-methods
 
 class GreyDilation(Filter):  # pylint: disable=too-few-public-methods
     """``scipy.ndimage.grey_dilation(image, size=...)``: flat maximum filter
-    (extension_filters.py:296-345).  Computed on the float32 values; returned in
-    the input's dtype."""
+    (extension_filters.py:296-345).  float32 and float64 rasters are dilated in their own
+    type (a maximum: exact either way); other types go through float64, which holds every
+    integer the reference's callers pass, and come back in the input's dtype."""
 
     def __init__(self, *, size):
         self.size = size
 
     def apply(self, image_to_filter):
         super().apply(image_to_filter)
-        img = backend.DeviceRaster.from_host(np.ascontiguousarray(image_to_filter,
-                                                                  dtype=np.float32))
-        out = backend.grey_dilation_dev(img, self.size)
-        if np.asarray(image_to_filter).dtype == np.float64:
-            return backend.widened_to_host(out, np.float64)
-        return out.to_host().astype(image_to_filter.dtype, copy=False)
+        src = np.asarray(image_to_filter)
+        work = np.float32 if src.dtype == np.float32 else np.float64
+        img = backend.DeviceRaster.from_host(np.ascontiguousarray(src, dtype=work))
+        out = backend.grey_dilation_dev(img, self.size).to_host()
+        img.free()
+        return out.astype(src.dtype, copy=False)

@@ -290,6 +290,9 @@ int hdem_expand_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int h, int w, int win
  * interleaved complex64 H x W array, in place; the inverse is unnormalised
  * (scipy's ifft2 = this / (H*W)). */
 int hdem_fft2_c2c_f32_dev(hdem_ctx *ctx, float *data, int H, int W, int inverse);
+/* ... and on an interleaved complex128 array: what scipy.fftpack computes for float64 /
+ * complex128 input (extension_filters.py:379,414).  Plan made and released per call. */
+int hdem_fft2_c2c_f64_dev(hdem_ctx *ctx, double *data, int H, int W, int inverse);
 
 /* ---- SURVEY 8f-3  HydroSHEDS / lagoon branch --------------------------------
  * CorrectNANValues.apply (custom_filters.py:287-317): cells < 0 whose `window` (odd, 3..11;
@@ -315,6 +318,8 @@ int hdem_binary_closing_u8_dev(hdem_ctx *ctx, const uint8_t *mask, int H, int W,
  * maximum filter, mode 'reflect', odd sizes. */
 int hdem_grey_dilation_f32_dev(hdem_ctx *ctx, const float *img, int H, int W, int sy, int sx,
                                float *out);
+int hdem_grey_dilation_f64_dev(hdem_ctx *ctx, const double *img, int H, int W, int sy, int sx,
+                               double *out);
 /* TidyingLagoons.apply (:564-610) and LagoonsDetection.apply (:613-661), device
  * resident.  fixed / values (may be NULL): the reference's hsheds_nan_fixed and
  * lagoons_values; mask: 1 where lagoons_values > 0. */
@@ -338,6 +343,8 @@ int hdem_boxmean3_f64_dev(hdem_ctx *ctx, const double *x, int H, int W,
 /* general odd kh x kw weights (host pointer, row-major doubles), <= 15x15 */
 int hdem_convolve_f32(hdem_ctx *ctx, const float *x, int H, int W,
                       const double *weights, int kh, int kw, float *out);
+int hdem_convolve_f64(hdem_ctx *ctx, const double *x, int H, int W,
+                      const double *weights, int kh, int kw, double *out);
 int hdem_around_f32(hdem_ctx *ctx, const float *x, int64_t n, float *out);
 int hdem_around_f64(hdem_ctx *ctx, const double *x, int64_t n, double *out);
 

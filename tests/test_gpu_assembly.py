@@ -88,13 +88,18 @@ def test_composed_filter_results_keeps_stages_on_the_device(gold):
     chain = Chain()
     last = chain.apply_device(backend.DeviceRaster.from_host(gold["probe"]))
     assert set(chain.results.keys()) == {"GreaterThan", "BooleanToInteger", "ProductFilter"}
-    assert dict.__len__(chain.results) == 0                 # nothing downloaded yet
+    assert chain.results.downloaded() == []                 # nothing downloaded yet
+    assert len(chain.results) == 3 and chain.results.get("Around") is None
     assert np.array_equal(chain.results["GreaterThan"], gold["positives"])
-    assert dict.__len__(chain.results) == 1
+    assert chain.results.downloaded() == ["GreaterThan"]
+    assert np.array_equal(chain.results.get("BooleanToInteger"), gold["positives"])
+    assert [k for k, _ in chain.results.items()] == list(chain.results)
     assert np.array_equal(last.to_host(), gold["positives"] * 3.0)
     with pytest.raises(KeyError):
         chain.results["Around"]                             # pylint: disable=pointless-statement
-    chain.results.release()
+    chain.results.release(keep=last)                        # the caller's raster survives
+    assert np.array_equal(last.to_host(), gold["positives"] * 3.0)
+    last.free()
     # the host form is the reference's: every stage a host array, stored eagerly
     host = Chain()
     host.apply(gold["probe"])

@@ -146,3 +146,50 @@ def test_rccl_backend_world_of_one(tmp_path, built):
     got = np.load(tmp_path / "r0.npz")
     want = c_oracle.sinkfill_pflood(oracle.synth_dem(H, W))
     assert np.array_equal(got["w"], want) and np.array_equal(got["d"], c_oracle.d8(want))
+
+
+@pytest.mark.parametrize("world,rows,cols,holes", [(4, 1024, 2100, False), (3, 700, 1000, True),
+                                                   (8, 512, 1300, False)])
+def test_partition_hub_start_bounds_the_fill(built, world, rows, cols, holes):
+    """The start values of the partitioned fill -- ONE hub graph over all ranks
+    (partition.hub_start): every rank's d, the seam rows of d swapped into the ghost rows, the
+    ranks' hub rasters stacked and filled, levels handed back -- are upper bounds of the fill,
+    cell by cell, on every rank: u = max(d, level of the cell's tile) >= the C oracle, ghost
+    rows included.  Widths that leave a partial last tile column, nodata across a seam."""
+    from hydrodem_amd import backend, partition as P
+    h, t = world * rows, 62
+    z = oracle.synth_dem(h, cols)
+    if holes:
+        z[rows - 20:rows + 30, 300:420] = np.nan
+        z[2 * rows + 3, 77] = np.nan
+    want = c_oracle.sinkfill_pflood(z)
+    ghost = P.ghost_rows(world, h)
+
+    def body(rank, comm):
+        g0, g1, top, bottom = P.local_range(rank, world, h, ghost)
+        zt = torch.from_numpy(z[g0:g1]).cuda()
+        w = torch.empty_like(zt)
+        solver = P.HipLocalSolver(0, turn=comm.gpu_turn)
+        flags = (backend.FILL_GHOST_TOP if top else 0) | (backend.FILL_GHOST_BOTTOM if bottom else 0)
+        levels = P.hub_start(zt, w, comm, solver, flags, ghost)
+        torch.cuda.synchronize()
+        d, lev = w.cpu().numpy(), levels.cpu().numpy()
+        solver.ctx.close()
+        hh, ww = d.shape
+        per_cell = np.repeat(np.repeat(lev[1::2, 1::2], t, axis=0), t, axis=1)[:hh - 2, :ww - 2]
+        per_cell = np.where(per_cell >= 3e38, np.inf, per_cell)
+        u = d.copy()
+        inner = u[1:-1, 1:-1]
+        u[1:-1, 1:-1] = np.where(np.isnan(per_cell) | np.isnan(inner), inner,
+                                 np.maximum(inner, per_cell))
+        low = u < want[g0:g1]                       # (NaN compares false: nodata stays out)
+        low[:, 0] = low[:, -1] = False              # raster ring columns: written by the fill
+        if not top:
+            low[0] = False
+        if not bottom:
+            low[-1] = False
+        return int(low.sum()), float(np.mean(u[1:-1, 1:-1] == want[g0:g1][1:-1, 1:-1]))
+
+    got = P.ThreadWorld(world).run(body)
+    assert [g[0] for g in got] == [0] * world, f"start values below the fill: {got}"
+    assert min(g[1] for g in got) > 0.3             # and tight: a third of the cells exact

@@ -15,6 +15,8 @@ undivided raster: about four minutes of host work per 10^9 cells, which is why t
 oracles start in background threads when the session starts (conftest.py: fixture
 ``big``) and this file sorts last among the GPU tests.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -85,7 +87,7 @@ def test_config3_chain_groves_fill_d8_at_16384(built):
 # --------------------------------------------------------------------------
 # configs 4 and 5: the multi-GPU partitions on virtual ranks
 # --------------------------------------------------------------------------
-def _partitioned_fill(z, world):
+def _partitioned_fill(z, world, rows_per_rank=8192):
     import torch
     from hydrodem_amd import partition as P
     h = z.shape[0]
@@ -94,7 +96,7 @@ def _partitioned_fill(z, world):
 
     def rank_body(rank, comm):
         g0, g1, _, _ = P.local_range(rank, world, h, ghost)
-        assert P.row_range(rank, world, h)[1] - P.row_range(rank, world, h)[0] == 8192
+        assert P.row_range(rank, world, h)[1] - P.row_range(rank, world, h)[0] == rows_per_rank
         zt = torch.from_numpy(z[g0:g1]).cuda()
         codes = torch.empty(zt.shape, dtype=torch.uint8, device=zt.device)
         solver = P.HipLocalSolver(0, turn=comm.gpu_turn)
@@ -126,6 +128,56 @@ def test_multi_gpu_partition_on_virtual_ranks_bit_exact(big, case):
         assert info["exchanges"] >= 2 and info["verifications"] >= 1
         assert st["async_timed_out"] == 0
     print(case, "exchanges", got[0][2]["exchanges"], "visits/rank",
+          [g[2]["tile_visits"] for g in got])
+
+
+def test_eight_ranks_at_config5_width_bit_exact(big):
+    """Eight row blocks of 65536 columns -- every middle rank has two neighbours, the seam
+    rows are config 5's 256 KiB -- on the raster whose oracle the two-block case already has:
+    2048 rows per rank.  The partition starts from ONE hub graph over all ranks
+    (partition.hub_start), which is what this checks at width."""
+    h, w, _ = CASES["config5"]
+    z, want_w, want_d = big["config5"].result()
+    got = _partitioned_fill(z, 8, rows_per_rank=h // 8)
+    from hydrodem_amd import partition as P
+    for rank, (w_own, d_own, info, st) in enumerate(got):
+        r0, r1 = P.row_range(rank, 8, h)
+        assert np.array_equal(w_own, want_w[r0:r1]), f"fill of rank {rank} differs"
+        assert np.array_equal(d_own, want_d[r0:r1]), f"D8 of rank {rank} differs"
+        assert info["start_values"] == "hub" and st["async_timed_out"] == 0
+    print("8 ranks x 2048 x 65536: exchanges", got[0][2]["exchanges"], "visits/rank",
+          [g[2]["tile_visits"] for g in got])
+
+
+@pytest.mark.skipif(not os.environ.get("HDEM_TEST_CONFIG5_WHOLE"),
+                    reason="config 5 whole (65536^2: 16 GiB per array, ~4 min of host time to "
+                           "generate the raster) runs on request: HDEM_TEST_CONFIG5_WHOLE=1; the "
+                           "default-on tests cover its blocks at full width")
+def test_config5_whole_on_eight_virtual_ranks():
+    """BASELINE configs[4] at its size on one GPU: 65536 x 65536, eight virtual ranks of
+    8192 x 65536 (+ overlap rows) through partition.sinkfill_distributed, against the SAME
+    raster filled undivided on the same GPU (another schedule, another start graph: the
+    two agree bit for bit), plus W >= Z and per-block idempotence.  No CPU oracle at this
+    size (the C flood would take ~12 min and ~90 GiB)."""
+    import torch
+    from hydrodem_amd import partition as P
+    n, world = 65536, 8
+    z = oracle.synth_dem(n, n)
+    zd = backend.DeviceRaster.from_host(z)
+    wd, codes, st = backend.sinkfill_d8_dev(zd)
+    assert st["converged"] and st["async_timed_out"] == 0
+    zd.free()
+    whole_w, whole_d = wd.to_host(), codes.to_host()
+    wd.free()
+    codes.free()
+    assert (whole_w >= z).all()
+    got = _partitioned_fill(z, world)
+    for rank, (w_own, d_own, info, st) in enumerate(got):
+        r0, r1 = P.row_range(rank, world, n)
+        assert np.array_equal(w_own, whole_w[r0:r1]), f"fill of rank {rank} differs"
+        assert np.array_equal(d_own, whole_d[r0:r1]), f"D8 of rank {rank} differs"
+        assert info["start_values"] == "hub"
+    print("config 5 whole: exchanges", got[0][2]["exchanges"], "visits/rank",
           [g[2]["tile_visits"] for g in got])
 
 
