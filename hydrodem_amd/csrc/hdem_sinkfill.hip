@@ -1031,9 +1031,9 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
         int rr = 0;
 #pragma unroll
         for (int r = FT; r >= 1; --r) rr = z[r] == hz ? r : rr;
-        const int R = __builtin_amdgcn_readlane(rr, L);
+        rr = lane == L ? rr : -1;                   // (the first lane with the minimum, its first row)
 #pragma unroll
-        for (int r = 1; r <= FT; ++r) w[r] = (lane == L && r == R) ? hz : HDEM_INF;
+        for (int r = 1; r <= FT; ++r) w[r] = rr == r ? hz : HDEM_INF;
     }
     float zt[WN];
 #pragma unroll
@@ -1734,7 +1734,13 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         }
     }
     float coarse_add = 0.0f;
-    if (!(flags & HDEM_FILL_WARM) && !hub_lev && (eps == 0.0f || !ctx->start_coarse)) {
+    // (eps > 0: the block-maximum start below is valid and keeps the bits -- tested -- but the
+    // launch behind it takes 14 instead of 9 ms at 16384^2: a bound that is flat inside every
+    // block, under a surface that climbs cell by cell, has every tile relax many times while
+    // the values from the outlets are still on their way; from +inf the tiles run in the order
+    // the flood reaches them.  Off unless HDEM_FILL_EPS_COARSE is set.)
+    const bool eps_coarse = eps != 0.0f && !ctx->start_coarse && getenv("HDEM_FILL_EPS_COARSE");
+    if (!(flags & HDEM_FILL_WARM) && !hub_lev && (eps == 0.0f || eps_coarse)) {
         if (ctx->start_coarse) {
             coarse = ctx->start_coarse;
             row_map = ctx->start_row_map;

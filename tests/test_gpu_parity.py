@@ -572,6 +572,46 @@ def test_hub_start_gives_the_same_bits(monkeypatch, shape, variant, holes):
         r.free()
 
 
+@pytest.mark.parametrize("n,eps,variant", [(4096, 1e-4, "rough"), (2048, 1e-3, "rough"),
+                                           (2048, 1e-4, "srtm"), (1500, 0.01, "rough")])
+def test_gradient_fill_from_the_coarse_start(monkeypatch, n, eps, variant):
+    """eps > 0 (Planchon-Darboux gradient; BASELINE config 5's "to 1e-4 m" reading) from a
+    coarse start: the block-maximum raster filled with a gradient of its own -- b (eps + ulp) +
+    ulp per coarse step for b x b blocks, the float32 rounding of every fine addition allowed
+    for (hdem_sinkfill.hip).  Same bits as the C flood, and the start values themselves bound
+    it from above.  Built for VERDICT r2 #4 and measured SLOWER than the +inf start (14 against
+    9 ms at 16384^2), so it is off unless HDEM_FILL_EPS_COARSE is set; this test
+    keeps it honest.  The default path at eps > 0 is the first assertion block as well: the
+    same raster without the switch."""
+    monkeypatch.setenv("HDEM_COARSE_MIN_CELLS", "1")
+    monkeypatch.setenv("HDEM_FILL_EPS_COARSE", "1")
+    z = oracle.synth_dem(n, n, variant=variant)
+    z[n // 3, n // 2] = np.nan
+    want = c_oracle.sinkfill_pflood(z, eps=eps)
+    ctx = backend.context()
+    ctx.profile(True)
+    ctx.profile_reset()
+    zd = backend.DeviceRaster.from_host(z)
+    wd, codes, st = backend.sinkfill_d8_dev(zd, eps=eps)
+    coarse_launches = ctx.profile_get(backend.K_FILL_COARSE)["launches"]
+    ctx.profile(False)
+    assert coarse_launches == 1 and st["converged"] and st["async_timed_out"] == 0
+    assert np.array_equal(wd.to_host(), want, equal_nan=True)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    monkeypatch.setenv("HDEM_FILL_TEST_BUDGET_US", "0")          # the start values, no visit
+    ud, _ = backend.sinkfill_dev(zd, eps=eps, flags=backend.FILL_INIT | backend.FILL_NO_VERIFY)
+    u = ud.to_host()
+    ok = np.isnan(want) | (u >= want)
+    assert ok.all(), f"{int((~ok).sum())} start values below the gradient fill"
+    assert np.median((u - want)[~np.isnan(want)]) < 5.0         # and they are bounds worth having
+    monkeypatch.delenv("HDEM_FILL_TEST_BUDGET_US")
+    monkeypatch.delenv("HDEM_FILL_EPS_COARSE")                   # the default: from +inf
+    wd2, st2 = backend.sinkfill_dev(zd, eps=eps)
+    assert np.array_equal(wd2.to_host(), want, equal_nan=True) and st2["converged"]
+    for r in (zd, wd, codes, ud, wd2):
+        r.free()
+
+
 def test_time_sliced_fill_resumes_to_the_same_bits():
     """INIT with a short time slice leaves tiles queued; RESUME continues the same
     worklist; the result and a final certifying pass agree with the oracle."""

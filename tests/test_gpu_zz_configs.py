@@ -5,7 +5,9 @@ BASELINE.json's configurations at their exact sizes, on one GPU (default-on):
   config 3   16384 x 16384, the chain groves x3 -> sink fill -> D8, checked *as a chain*
   config 4   32768 x 32768 cut into the 4 row blocks of 8192 (+ overlap) rows the 4-GPU run
              uses, solved by `partition.sinkfill_distributed` itself on 4 virtual ranks
-  config 5   row blocks of 8192 x 65536 (what each of the 8 GPUs holds), two of them
+  config 5   row blocks of 8192 x 65536 (what each of the 8 GPUs holds): two of them and,
+             at 2048 rows each, eight of them against the C oracle; and the WHOLE 65536 x 65536
+             mosaic on eight virtual ranks against the same raster filled undivided
 
 Configs 4 and 5 run the distributed schedule unchanged -- coarse start, local solves,
 seam exchanges, votes, certifying pass -- with threads for ranks and device row copies
@@ -149,16 +151,16 @@ def test_eight_ranks_at_config5_width_bit_exact(big):
           [g[2]["tile_visits"] for g in got])
 
 
-@pytest.mark.skipif(not os.environ.get("HDEM_TEST_CONFIG5_WHOLE"),
-                    reason="config 5 whole (65536^2: 16 GiB per array, ~4 min of host time to "
-                           "generate the raster) runs on request: HDEM_TEST_CONFIG5_WHOLE=1; the "
-                           "default-on tests cover its blocks at full width")
+@pytest.mark.skipif(os.environ.get("HDEM_SKIP_CONFIG5_WHOLE") == "1",
+                    reason="HDEM_SKIP_CONFIG5_WHOLE=1 (the test holds ~60 GiB of host arrays: "
+                           "the 16 GiB raster, the undivided result, the ranks' blocks)")
 def test_config5_whole_on_eight_virtual_ranks():
     """BASELINE configs[4] at its size on one GPU: 65536 x 65536, eight virtual ranks of
     8192 x 65536 (+ overlap rows) through partition.sinkfill_distributed, against the SAME
     raster filled undivided on the same GPU (another schedule, another start graph: the
     two agree bit for bit), plus W >= Z and per-block idempotence.  No CPU oracle at this
-    size (the C flood would take ~12 min and ~90 GiB)."""
+    size (the C flood would take ~12 min and ~90 GiB).  17 s on the GPU box, most of it the
+    raster's generation."""
     import torch
     from hydrodem_amd import partition as P
     n, world = 65536, 8
