@@ -29,6 +29,7 @@
 #include "hdem_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -162,10 +163,12 @@ __global__ __launch_bounds__(NT) void groves_kernel(const float *__restrict__ im
 constexpr int SW_COLS = 256;     // strip width  (cells) = 64 lanes x 4
 constexpr int SR_ROWS = 128;     // strip height (output rows) unless the launch picks another
 
-// (at least 3 waves per SIMD: ws = 15 then fits 168 registers with 5 of them spilled,
-// and runs 6 % faster than at 183 registers and 2 waves)
+// (two waves per SIMD.  Rounds 1-2 ran three at 168 registers with a few of them spilled, which
+// was 6 % faster than 183 registers and two waves THEN; with the vertical box sum through a
+// prefix -- 10 % fewer vector instructions -- the three-wave build spills 47 scratch accesses
+// per 15 rows and gains nothing, the two-wave build is 8 % faster: 1.85 against 2.02 ms)
 template <int WS>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void groves_stream_kernel(const float *__restrict__ img,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void groves_stream_kernel(const float *__restrict__ img,
                                                           const uint8_t *__restrict__ groves,
                                                           int H, int W, float thr,
                                                           int strips_x, int nstrips, int strip_rows,
@@ -176,11 +179,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
     constexpr int OFF = PADL - P;                         // first needed float, from the aligned read
     constexpr int NRD = (OFF + 4 + 2 * P + 3) / 4;        // ds_read_b128 per lane per row
     constexpr int RB = (PADL + SW_COLS + P + 3) / 4 * 4 + 4;   // row buffer (floats)
-    constexpr int PF = 3;                                 // rows in flight (divides the unroll)
+    constexpr int PF = WS % 5 == 0 ? 5 : 3;               // rows in flight (divides the unroll)
     static_assert(WS % PF == 0 || WS < PF, "prefetch ring must divide the unroll");
     constexpr int NSLOT = 8;                              // >= p + 1 rows of history (ws <= 15)
     static_assert(P + 1 <= NSLOT, "row ring too short");
     __shared__ __attribute__((aligned(16))) float rows[4][NSLOT][RB];
+    // the lane's own four raw cells of the same rows: the epilogue needs the untouched centre
+    // value (the row buffer holds d = w - c0, subtracted once by the lane that wrote the cell
+    // instead of by every lane that reads it: 5 instead of 20 subtractions per lane-row)
+    __shared__ __attribute__((aligned(16))) float raw[4][NSLOT][SW_COLS];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
     const int x0 = sx * SW_COLS, y0 = sy * strip_rows;
     const int x = x0 + 4 * lane;
     float *rb = &rows[wave][0][0];
+    float *rw = &raw[wave][0][0];
     const bool vec_ok = x + 4 <= W;
 
     float c0 = img[(size_t)min(y0 + strip_rows / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
@@ -232,36 +240,61 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
         return g;
     };
 
+    // R2 enters all ws pending output rows with weight 1 -- a vertical box sum.  Instead of ws
+    // packed adds per row: one running prefix PT of the rows' R2 inside the current block of ws
+    // rows (the unrolled loop body).  A slot is opened at -PT, takes +PT(end of block) when the
+    // block ends (ws adds once per ws rows) and +PT once more when it completes: 4 packed
+    // operations per row and column pair instead of ws, and every sum still has <= ws terms.
+    f2 pt[2] = {(f2){0.0f, 0.0f}, (f2){0.0f, 0.0f}};
+
     hdem_f4 pre[PF];
     float preh[PF];
     unsigned preg[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) { load_row(k, pre[k], preh[k]); preg[k] = load_mask(k); }
 
+    // One row ahead through LDS: iteration i puts row i + 1 into its slot and asks for the
+    // 4 + 2p values around the lane's columns, and works on row i, whose values arrived during
+    // iteration i - 1 -- the LDS round trip is off the row's critical path.
+    auto stage_row = [&](int i, const hdem_f4 &v, float hv) {
+        float *slot = rb + (i & (NSLOT - 1)) * RB;          // d = w - c0 of image row i
+        *reinterpret_cast<hdem_f4 *>(rw + (i & (NSLOT - 1)) * SW_COLS + 4 * lane) = v;
+        const hdem_f4 dv = {v[0] - c0, v[1] - c0, v[2] - c0, v[3] - c0};
+        *reinterpret_cast<hdem_f4 *>(slot + PADL + 4 * lane) = dv;
+        if (has_halo) slot[hidx] = hv - c0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto read_row = [&](int i, float (&d)[NRD * 4]) {
+        const float *slot = rb + (i & (NSLOT - 1)) * RB;
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) {
+            const hdem_f4 q = *reinterpret_cast<const hdem_f4 *>(slot + 4 * lane + 4 * k);
+            d[4 * k] = q[0]; d[4 * k + 1] = q[1];
+            d[4 * k + 2] = q[2]; d[4 * k + 3] = q[3];
+        }
+    };
+    float d[NRD * 4];
+    stage_row(0, pre[0], preh[0]);
+    load_row(PF, pre[0], preh[0]);
+    read_row(0, d);
+
     const int NROWS = strip_rows + 2 * P;
     for (int base = 0; base < NROWS; base += WS) {
 #pragma unroll
         for (int u = 0; u < WS; ++u) {
             const int i = base + u;
-            // ---- row i: registers -> LDS row slot, next prefetch ------------------
-            float *slot = rb + (i & (NSLOT - 1)) * RB;      // raw image row i
-            const hdem_f4 v = pre[u % PF];
-            const float hv = preh[u % PF];
             const unsigned g4 = preg[u % PF];
-            *reinterpret_cast<hdem_f4 *>(slot + PADL + 4 * lane) = v;
-            if (has_halo) slot[hidx] = hv;
-            load_row(i + PF, pre[u % PF], preh[u % PF]);
             preg[u % PF] = load_mask(i + PF);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- 4 + 2p values around my columns ------------------------------------
-            float d[NRD * 4];
-#pragma unroll
-            for (int k = 0; k < NRD; ++k) {
-                const hdem_f4 q = *reinterpret_cast<const hdem_f4 *>(slot + 4 * lane + 4 * k);
-                d[4 * k] = q[0] - c0; d[4 * k + 1] = q[1] - c0;
-                d[4 * k + 2] = q[2] - c0; d[4 * k + 3] = q[3] - c0;
-            }
+            // the raw centre row of the output that completes now (input row i - p): read
+            // before row i + 1 takes that slot of the ring
+            const hdem_f4 wq = *reinterpret_cast<const hdem_f4 *>(
+                rw + ((i - P) & (NSLOT - 1)) * SW_COLS + 4 * lane);
+            // ---- row i + 1: registers -> LDS, its values on their way, next prefetch ----
+            float dn[NRD * 4];
+            stage_row(i + 1, pre[(u + 1) % PF], preh[(u + 1) % PF]);
+            load_row(i + 1 + PF, pre[(u + 1) % PF], preh[(u + 1) % PF]);
+            read_row(i + 1, dn);
             // ---- row sums, then into the ring of vertical accumulators --------------
             // Moments instead of four 15-tap sums: with v_k = k + v0 the weighted row sum is
             // sum v_k^2 d = M2 + 2 v0 M1 + v0^2 M0 (M_i = sum k^i d), and the three moments
@@ -301,8 +334,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
                 // (all the adds, then all the fmas: written as add-then-fma per slot the
                 // compiler reuses one temporary, and a packed fma that consumes the packed
                 // add just before it needs a wait state -- 30 s_nop per row)
-#pragma unroll
-                for (int j = 0; j < WS; ++j) acc[j][p2] += t;
+                pt[p2] += t;
 #pragma unroll
                 for (int j = 0; j < WS; ++j) {
                     // output row (i - j) sits in slot (u - j) mod WS and takes weight cy[j]
@@ -313,13 +345,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
             }
             // ---- output row i - 2p is complete: blend and store ------------------------
             const int done = (u + 1) % WS;            // slot of output row i - (WS - 1)
+            if (u == WS - 1) {
+                // the block ends: its R2 total goes to every open slot (the completing one
+                // opened with the block), and the prefix starts again
+#pragma unroll
+                for (int j = 0; j < WS; ++j) { acc[j][0] += pt[0]; acc[j][1] += pt[1]; }
+                pt[0] = (f2){0.0f, 0.0f};
+                pt[1] = (f2){0.0f, 0.0f};
+            } else {
+                acc[done][0] += pt[0];
+                acc[done][1] += pt[1];
+            }
             const int oy = i - 2 * P, y = y0 + oy;
             if (oy >= 0 && oy < strip_rows && y < H && x < W) {
                 const size_t gi = (size_t)y * W + x;
                 float o4[4];
-                // the centre row of this output (input row i - p) is still in the ring, raw
-                const hdem_f4 wq = *reinterpret_cast<const hdem_f4 *>(
-                    rb + ((i - P) & (NSLOT - 1)) * RB + PADL + 4 * lane);
                 const float wv[4] = {wq[0], wq[1], wq[2], wq[3]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -347,8 +387,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void gr
                         if (x + k < W) out[gi + k] = o4[k];
                 }
             }
-            acc[done][0] = (f2){0.0f, 0.0f};
-            acc[done][1] = (f2){0.0f, 0.0f};
+            // the slot opens again for the output row that starts with the next input row
+            acc[done][0] = -pt[0];
+            acc[done][1] = -pt[1];
+#pragma unroll
+            for (int k = 0; k < NRD * 4; ++k) d[k] = dn[k];
         }
     }
 }
@@ -377,12 +420,12 @@ void launch_ws(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, in
                float thr, const quad_coef &cf, float *out)
 {
     if constexpr (WS == 15 || WS == 9 || WS == 3) {      // streaming form (prefetch ring | ws)
-        // Strip height: every strip is one wave's serial walk, and the machine holds 12 of them
-        // per CU (three waves per SIMD) -- a count of strips just above a multiple of that leaves
+        // Strip height: every strip is one wave's serial walk, and the machine holds 8 of them
+        // per CU (two waves per SIMD) -- a count of strips just above a multiple of that leaves
         // the last round nearly empty (16384^2 at 128 rows: 8192 strips on 3072 places, 2.67
         // rounds).  Among the heights from 96 to 192 rows take the one whose last round is
         // fullest, ties to the taller (less overlap between strips).
-        const int sx = (W + SW_COLS - 1) / SW_COLS, places = ctx->num_cus * 12;
+        const int sx = (W + SW_COLS - 1) / SW_COLS, places = ctx->num_cus * (getenv("HDEM_GROVES_PLACES") ? atoi(getenv("HDEM_GROVES_PLACES")) : 8);
         int rows = SR_ROWS;
         double best = -1.0;
         for (int cand = 96; cand <= 192; ++cand) {
