@@ -103,3 +103,58 @@ def test_large_results_come_back_in_reused_page_locked_blocks(built):
     d2 = d.copy()
     d[:] = 0
     assert d2.sum() > 0
+
+
+def test_trim_returns_the_cache_and_the_scratch(built):
+    """hdem_trim: cached blocks and the scratch buffers the context keeps between calls go
+    back to the device (a process that shares the GPU with another allocator), the context
+    stays usable and grows them back."""
+    ctx = backend.Context(0)
+    z = oracle.synth_dem(1200, 1100)
+    zd = backend.DeviceRaster.from_host(z, ctx=ctx)
+    w, _ = backend.sinkfill_dev(zd)                        # hub buffers, workspace
+    want = w.to_host()
+    w.free()                                               # parked in the cache
+    released = ctx.trim()
+    assert released >= z.nbytes                            # at least the parked raster
+    assert ctx.trim() == 0                                 # nothing left to give
+    w2, _ = backend.sinkfill_dev(zd)
+    assert np.array_equal(w2.to_host(), want)
+    for r in (zd, w2):
+        r.free()
+    ctx.close()
+
+
+def test_two_contexts_and_a_changed_stream(built):
+    """The cache's contract is single-stream (include/hydrodem_hip.h): a raster of context A
+    that context B works on is synchronised on B by the caller before A frees it -- then A may
+    hand the block out again at once -- and a context whose stream was changed since a block
+    was handed out waits for the device when the block comes back."""
+    import torch
+    a, b = backend.Context(0), backend.Context(0)
+    z = oracle.synth_dem(900, 1000)
+    want = c_oracle.boxmean3(z, True)
+    for _ in range(3):
+        za = backend.DeviceRaster.from_host(z, ctx=a)
+        # B's operator reads A's raster (wrapped: B does not own it)
+        seen = backend.DeviceRaster.wrap(za.ptr, za.shape, np.float32, ctx=b, keepalive=za)
+        out_b = backend.boxmean3_dev(seen)
+        b.synchronize()                                    # the caller's part of the contract
+        block = za.ptr
+        za.free()
+        again = backend.DeviceRaster.from_host(np.zeros_like(z), ctx=a)     # takes the block over
+        assert again.ptr == block
+        assert np.array_equal(out_b.to_host(), want)
+        again.free()
+        out_b.free()
+    # a block handed out under the context's own stream, freed under a caller's stream
+    blk = backend.DeviceRaster.from_host(z, ctx=a)
+    side = torch.cuda.Stream()
+    a.set_stream(side.cuda_stream)
+    res = backend.boxmean3_dev(blk)                        # runs on the caller's stream
+    blk.free()                                             # stream changed: device-wide wait
+    assert np.array_equal(res.to_host(), want)
+    res.free()
+    a.set_stream(None)
+    a.close()
+    b.close()

@@ -6,9 +6,13 @@ instead of stale when the kernel changes.
 usage: python tools/record_traffic.py <fetch.csv> <write.csv> <size> [out.json]
        (the CSVs are outputs of tools/summarize_pmc.py)
 
-FETCH_SIZE is in KB and under-reports on gfx950: x2 for 16-byte-per-lane streaming reads
-(the guide), x1.605 for the 4-byte-per-lane row loads of the tile visit -- calibrated on a kernel
-of the same access shape that reads a known 1.0737 GB; WRITE_SIZE (KB) is exact."""
+FETCH_SIZE is in KB and reports exactly half of the bytes on gfx950 (the guide: 128-byte
+requests tallied at 64 B).  Round 3 measured it for both load shapes of this library with a
+kernel that reads a known 1.0737 GB once (tools/micro/fetch_calib.hip,
+profiles/r03_fetch_calibration.csv): 524 310 KB for one dword per lane and 256-byte row pieces
+-- the tile visit's shape -- and 524 298 KB for 16-byte vectors: x2.00 for both.  (Rounds 1-2
+used x1.605, from a window-load benchmark whose overlapping windows were partly served by L2.)
+WRITE_SIZE (KB) is exact."""
 import csv
 import json
 import os
@@ -19,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-FETCH_FACTOR = 1.605
+FETCH_FACTOR = 2.0
 
 
 def per_dispatch(path, counter):
@@ -43,7 +47,7 @@ def main():
            "dispatches": [n_f, n_w],
            "source": f"{os.path.relpath(fetch_csv, ROOT)}, {os.path.relpath(write_csv, ROOT)}: "
                      f"separate rocprofv3 --pmc passes of bench.py, bytes per launch, "
-                     f"FETCH_SIZE x{FETCH_FACTOR} (gfx950 calibration, 4-byte-per-lane loads)"}
+                     f"FETCH_SIZE x{FETCH_FACTOR} (gfx950: tools/micro/fetch_calib.hip)"}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
