@@ -612,6 +612,36 @@ def test_gradient_fill_from_the_coarse_start(monkeypatch, n, eps, variant):
         r.free()
 
 
+@pytest.mark.parametrize("kind", ["all_nodata", "constant", "one_pit", "nodata_ring", "stairs"])
+def test_hub_start_degenerate_rasters(monkeypatch, kind):
+    """Rasters on which the hub graph has nothing to stand on: no data at all (every tile an
+    outlet-less wall), one flat (every cell a hub candidate, every crossing a tie), a single
+    pit, nodata along the whole raster ring, integer stairs."""
+    monkeypatch.setenv("HDEM_HUB_MIN_TILES", "1")
+    h, w = 200, 330
+    rng = np.random.default_rng(3)
+    if kind == "all_nodata":
+        z = np.full((h, w), np.nan, np.float32)
+    elif kind == "constant":
+        z = np.full((h, w), 7.0, np.float32)
+    elif kind == "one_pit":
+        z = np.full((h, w), 50.0, np.float32) + rng.random((h, w)).astype(np.float32)
+        z[100, 150] = -4.0
+    elif kind == "nodata_ring":
+        z = oracle.synth_dem(h, w)
+        z[0], z[-1], z[:, 0], z[:, -1] = np.nan, np.nan, np.nan, np.nan
+    else:
+        z = np.add.outer(np.arange(h) // 9, np.arange(w) // 13).astype(np.float32)
+        z[60:90, 100:140] -= 3.0
+    want = c_oracle.sinkfill_pflood(z)
+    wd, codes, st = backend.sinkfill_d8_dev(backend.DeviceRaster.from_host(z))
+    assert st["converged"]
+    assert np.array_equal(wd.to_host(), want, equal_nan=True)
+    assert np.array_equal(codes.to_host(), c_oracle.d8(want))
+    wd.free()
+    codes.free()
+
+
 def test_time_sliced_fill_resumes_to_the_same_bits():
     """INIT with a short time slice leaves tiles queued; RESUME continues the same
     worklist; the result and a final certifying pass agree with the oracle."""
