@@ -370,6 +370,38 @@ def fill_line(B, ctx, z, workload, steps=10):
             "useful_frac": FLOOR_BYTES_PER_CELL * cells / ms / 1e6 / HBM_PEAK_GBS}
 
 
+def batch_line(B, ctx, n=16, edge=1201, reps=5):
+    """Sixteen SRTM-sized tiles (1201^2), resident: one fill + D8 call each, against all of them
+    in ONE call on a canvas with nodata gutters (what HydroConditioning.apply_batch launches;
+    same bits: nodata's neighbours are pinned like a raster ring)."""
+    import hdem_synth
+    tiles = [hdem_synth.synth_dem(edge, edge) + np.float32(k) for k in range(n)]
+    zs = [B.DeviceRaster.from_host(t, ctx=ctx) for t in tiles]
+    ws = [B.DeviceRaster.empty(t.shape, np.float32, ctx) for t in tiles]
+    ds = [B.DeviceRaster.empty(t.shape, np.uint8, ctx) for t in tiles]
+
+    def one_by_one():
+        for z, w, d in zip(zs, ws, ds):
+            B.sinkfill_d8_dev(z, out=w, codes=d)
+    ms_each = timed(ctx, one_by_one, reps)
+    for r in zs + ws + ds:
+        r.free()
+    canvas = np.full((n * (edge + 1) - 1, edge), np.nan, np.float32)
+    for k, t in enumerate(tiles):
+        canvas[k * (edge + 1):k * (edge + 1) + edge] = t
+    zc = B.DeviceRaster.from_host(canvas, ctx=ctx)
+    wc = B.DeviceRaster.empty(canvas.shape, np.float32, ctx)
+    dc = B.DeviceRaster.empty(canvas.shape, np.uint8, ctx)
+    ms_batch = timed(ctx, lambda: B.sinkfill_d8_dev(zc, out=wc, codes=dc), reps)
+    for r in (zc, wc, dc):
+        r.free()
+    cells = n * edge * edge
+    return {"workload": f"{n} rasters of {edge}x{edge}, SinkFill eps=0 + D8, resident",
+            "one_call_per_raster_ms": ms_each, "one_canvas_ms": ms_batch,
+            "Mcells_per_s_one_by_one": cells / ms_each / 1e3,
+            "Mcells_per_s_canvas": cells / ms_batch / 1e3}
+
+
 def config1(B, ctx):
     """BASELINE configs[0]'s raster on the GPU path: the reference's own 519 x 508 study-area
     DEM (cguerrero/resources/images/final_dem.tif, committed as tests/golden/ref_rasters.npz
@@ -613,6 +645,7 @@ def main():
             out["filters"] = filter_paths(B, ctx, zd, wd, S, copy_gbs, bool(a.cpu_sample))
             out["config2"] = config2(B, ctx)
             out["config1_raster"] = config1(B, ctx)
+            out["batch_of_tiles"] = batch_line(B, ctx)
         if a.cpu_sample and N == 1:
             out["cpu_baseline"] = cpu_baseline(z, a.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "hdem_memcpy_h2d": [_vp, _vp, _vp, _c.c_size_t],
     "hdem_memcpy_d2h": [_vp, _vp, _vp, _c.c_size_t],
     "hdem_memcpy_d2d": [_vp, _vp, _vp, _c.c_size_t],
+    "hdem_memset_dev": [_vp, _vp, _i, _c.c_size_t],
     "hdem_host_alloc": [_vp, _c.c_size_t, _c.POINTER(_vp)],
     "hdem_host_free": [_vp, _vp],
     "hdem_memcpy_h2d_async": [_vp, _vp, _vp, _c.c_size_t],

@@ -381,6 +381,17 @@ static int copy_async(hdem_ctx *ctx, void *dst, const void *src, size_t bytes, h
     return HDEM_OK;
 }
 
+// A byte fill on the context's stream (HydroConditioning.apply_batch makes its canvas of
+// nodata with it: 0xff bytes are a NaN).
+extern "C" int hdem_memset_dev(hdem_ctx *ctx, void *dptr, int byte, size_t bytes)
+{
+    HDEM_REQUIRE(ctx && (bytes == 0 || dptr), HDEM_ERR_BAD_ARG, "null argument");
+    if (!bytes) return HDEM_OK;
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMemsetAsync(dptr, byte, bytes, ctx->stream));
+    return HDEM_OK;
+}
+
 extern "C" int hdem_memcpy_h2d_async(hdem_ctx *c, void *d, const void *s, size_t n)
 { return copy_async(c, d, s, n, hipMemcpyHostToDevice); }
 extern "C" int hdem_memcpy_d2h_async(hdem_ctx *c, void *d, const void *s, size_t n)

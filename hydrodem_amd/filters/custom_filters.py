@@ -312,6 +312,65 @@ class HydroConditioning(ComposedFilter):  # pylint: disable=too-few-public-metho
                 self.filled = filled.to_host()
                 return codes.to_host()
 
+    def apply_batch(self, rasters):
+        """Fill + D8 of several rasters in ONE pass of the solver: ``[(filled, codes), ...]``.
+
+        Small rasters (SRTM / HydroSHEDS tiles are 1201^2 ... 6000^2 cells) leave most of the
+        GPU idle -- a fill is a chain of dependent tile visits -- so those of one width are
+        stacked into one canvas with a nodata row between neighbours.  That changes no result: the cells next to nodata are pinned exactly as
+        a raster's ring is (the operator's own rule), so every raster fills as it does alone;
+        only the D8 codes of each raster's ring are put back to 0 afterwards (on the canvas
+        they have neighbours).  The arrays returned are views of the downloaded canvases (one
+        pair of canvases per width).  Bit-equal to ``apply`` raster by raster
+        (``tests/test_gpu_parity.py::test_batch_of_rasters_fills_like_each_alone``)."""
+        rasters = [np.asarray(r, dtype=np.float32) for r in rasters]
+        for r in rasters:
+            Filter.apply(self, r)
+            if r.ndim != 2:
+                raise ValueError("apply_batch takes 2-D rasters")
+        if not rasters:
+            return []
+        rasters = [np.ascontiguousarray(r) for r in rasters]
+        ctx = backend.context()
+        lib, hnd = ctx.lib, ctx.handle
+        fill = self.filters[0]
+        out = [None] * len(rasters)
+        # one canvas per width (tiles of a survey share theirs): a raster then is one
+        # contiguous block of its canvas and goes up and comes down in one plain copy each
+        # (pitched copies from pageable memory run row by row: 30 x slower)
+        by_width = {}
+        for k, r in enumerate(rasters):
+            by_width.setdefault(r.shape[1], []).append(k)
+        stats = None
+        for width, members in by_width.items():
+            rows = sum(rasters[k].shape[0] for k in members) + len(members) - 1
+            with backend.DeviceRaster.empty((rows, width), np.float32, ctx) as z:
+                ctx.check(lib.hdem_memset_dev(hnd, z.ptr, 0xff, z.nbytes))      # all NaN
+                tops, y = [], 0
+                for k in members:
+                    r = rasters[k]
+                    ctx.check(lib.hdem_memcpy_h2d(hnd, z.ptr + y * width * 4, r.ctypes.data, r.nbytes))
+                    tops.append(y)
+                    y += r.shape[0] + 1
+                filled, codes, st = backend.sinkfill_d8_dev(z, eps=fill.epsilon,
+                                                            max_rounds=fill.max_rounds)
+                stats = st if stats is None else {
+                    key: (min(stats[key], st[key]) if key == "converged" else stats[key] + st[key])
+                    if isinstance(st[key], int) else st[key] for key in st}
+                with filled, codes:
+                    # the canvas comes down in two copies (page-locked blocks of the library,
+                    # backend.host_empty); what is handed out are views of it, one per raster
+                    # -- many small copies into fresh pageable arrays were measured at 200 ms
+                    # for 16 tiles, the driver pinning and unpinning their pages
+                    w_all, d_all = filled.to_host(), codes.to_host()
+                for k, y0 in zip(members, tops):
+                    h = rasters[k].shape[0]
+                    d = d_all[y0:y0 + h]
+                    d[0], d[-1], d[:, 0], d[:, -1] = 0, 0, 0, 0
+                    out[k] = (w_all[y0:y0 + h], d)
+        fill.stats = stats or {}
+        return out
+
 
 # ---------------------------------------------------------------------------
 # Fourier destripe (SURVEY 8f-1)

@@ -76,6 +76,9 @@ int hdem_trim(hdem_ctx *ctx, size_t *released);
 int hdem_memcpy_h2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2h(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
 int hdem_memcpy_d2d(hdem_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* A byte fill on the context's stream (0xff bytes make a raster of NaN: the canvas of
+ * HydroConditioning.apply_batch). */
+int hdem_memset_dev(hdem_ctx *ctx, void *dptr, int byte, size_t bytes);
 /* Raster I/O seam (utils_dem.py:17-40 reads / writes whole arrays):
  * page-locked host buffers and copies ordered on the context's stream, so that a band
  * of a raster can be read into pinned memory, processed and written back while the

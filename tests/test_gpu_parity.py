@@ -642,6 +642,24 @@ def test_hub_start_degenerate_rasters(monkeypatch, kind):
     codes.free()
 
 
+def test_batch_of_rasters_fills_like_each_alone():
+    """HydroConditioning.apply_batch: several rasters stacked into one canvas with nodata
+    gutters -- one launch -- give the bits each gives alone (fill and D8), whatever their
+    shapes, nodata of their own included."""
+    shapes = [(300, 410), (519, 508), (64, 700), (1201, 1201), (3, 5), (700, 333)]
+    rasters = [oracle.synth_dem(h, w, variant="srtm" if k % 2 else "rough")
+               for k, (h, w) in enumerate(shapes)]
+    rasters[1][100:110, 200:230] = np.nan
+    chain = hd.HydroConditioning()
+    got = chain.apply_batch(rasters)
+    assert chain.filters[0].stats["converged"]
+    for r, (w, d) in zip(rasters, got):
+        want = c_oracle.sinkfill_pflood(r)
+        assert np.array_equal(w, want, equal_nan=True)
+        assert np.array_equal(d, c_oracle.d8(want))
+    assert chain.apply_batch([]) == []
+
+
 def test_time_sliced_fill_resumes_to_the_same_bits():
     """INIT with a short time slice leaves tiles queued; RESUME continues the same
     worklist; the result and a final certifying pass agree with the oracle."""
