@@ -167,12 +167,18 @@ constexpr int SR_ROWS = 128;     // strip height (output rows) unless the launch
 // was 6 % faster than 183 registers and two waves THEN; with the vertical box sum through a
 // prefix -- 10 % fewer vector instructions -- the three-wave build spills 47 scratch accesses
 // per 15 rows and gains nothing, the two-wave build is 8 % faster: 1.85 against 2.02 ms)
-template <int WS>
+// FULL: every strip of the launch lies inside the raster's columns and W is a multiple of 4 --
+// no lane is ever out of range, every load and store is the vector form, and above all NO load
+// sits in a branch: with loads under per-lane conditions the compiler cannot count them and
+// waits for ALL outstanding memory operations (s_waitcnt vmcnt(0)) five times per row, which
+// drains the rows that were fetched ahead -- the general form runs that way, on the raster's
+// last strip column only.
+template <int WS, bool FULL>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void groves_stream_kernel(const float *__restrict__ img,
                                                           const uint8_t *__restrict__ groves,
                                                           int H, int W, float thr,
                                                           int strips_x, int nstrips, int strip_rows,
-                                                          quad_coef cf, float *__restrict__ out)
+                                                          int sx0, quad_coef cf, float *__restrict__ out)
 {
     constexpr int P = WS / 2;
     constexpr int PADL = (P + 3) / 4 * 4;                 // interior starts 16-byte aligned
@@ -192,12 +198,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip >= nstrips) return;
-    const int sy = strip / strips_x, sx = strip - sy * strips_x;
+    const int sy = strip / strips_x, sx = sx0 + strip - sy * strips_x;
     const int x0 = sx * SW_COLS, y0 = sy * strip_rows;
     const int x = x0 + 4 * lane;
     float *rb = &rows[wave][0][0];
     float *rw = &raw[wave][0][0];
-    const bool vec_ok = x + 4 <= W;
+    const bool vec_ok = FULL || x + 4 <= W;
 
     float c0 = img[(size_t)min(y0 + strip_rows / 2, H - 1) * W + min(x0 + SW_COLS / 2, W - 1)];
     if (!(fabsf(c0) < HDEM_INF)) c0 = 0.0f;
@@ -207,9 +213,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gr
     const int hx = min(max(lane < P ? x0 - P + lane : x0 + SW_COLS + lane - P, 0), W - 1);
     const int hidx = lane < P ? OFF + lane : PADL + SW_COLS + lane - P;
 
+    const int hxa = has_halo ? hx : x;                   // FULL: every lane loads a "halo" cell
     auto load_row = [&](int i, hdem_f4 &v, float &hv) {
         const int y = min(max(y0 - P + i, 0), H - 1);
         const float *row = img + (size_t)y * W;
+        if (FULL) {
+            v = hdem_ld4u(row + x);
+            hv = row[hxa];
+            return;
+        }
         if (x + 4 <= W) {
             v = hdem_ld4u(row + x);
         } else {
@@ -229,6 +241,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gr
     // PF steps ahead like the image rows: nothing in the loop waits on a fresh load
     auto load_mask = [&](int i) -> unsigned {
         const int y = y0 + i - 2 * P;
+        if (FULL)       // (a row outside the raster: any valid word, the epilogue skips the row)
+            return groves ? *reinterpret_cast<const unsigned *>(
+                                groves + (size_t)min(max(y, 0), H - 1) * W + x)
+                          : 0u;
         unsigned g = 0;
         if (groves && y >= 0 && y < H && x < W) {
             const size_t gi = (size_t)y * W + x;
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gr
                 acc[done][1] += pt[1];
             }
             const int oy = i - 2 * P, y = y0 + oy;
-            if (oy >= 0 && oy < strip_rows && y < H && x < W) {
+            if (oy >= 0 && oy < strip_rows && y < H && (FULL || x < W)) {
                 const size_t gi = (size_t)y * W + x;
                 float o4[4];
                 const float wv[4] = {wq[0], wq[1], wq[2], wq[3]};
@@ -435,9 +451,16 @@ void launch_ws(hdem_ctx *ctx, const float *img, const uint8_t *groves, int H, in
             const double eff = (double)H * sx / ((double)rounds * places * (cand + 2 * (WS / 2)));
             if (eff >= best) { best = eff; rows = cand; }
         }
-        const int sy = (H + rows - 1) / rows, n = sx * sy;
-        hipLaunchKernelGGL(groves_stream_kernel<WS>, dim3((n + 3) / 4), dim3(NT), 0, ctx->stream,
-                           img, groves, H, W, thr, sx, n, rows, cf, out);
+        const int sy = (H + rows - 1) / rows;
+        // strip columns that lie inside the raster take the branch-free form (see the kernel)
+        const int fx = (W % 4 == 0 && ((uintptr_t)groves % 4 == 0)) ? W / SW_COLS : 0;
+        if (fx > 0)
+            hipLaunchKernelGGL((groves_stream_kernel<WS, true>), dim3((fx * sy + 3) / 4), dim3(NT), 0,
+                               ctx->stream, img, groves, H, W, thr, fx, fx * sy, rows, 0, cf, out);
+        if (sx > fx)
+            hipLaunchKernelGGL((groves_stream_kernel<WS, false>), dim3(((sx - fx) * sy + 3) / 4),
+                               dim3(NT), 0, ctx->stream, img, groves, H, W, thr, sx - fx,
+                               (sx - fx) * sy, rows, fx, cf, out);
         return;
     }
     int tx = (W + GTW - 1) / GTW, ty = (H + GTH - 1) / GTH;
