@@ -39,6 +39,7 @@ _EW_TYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8
 FILL_INIT, FILL_WARM, FILL_ACT_TOP, FILL_ACT_BOTTOM = 0, 1, 2, 4
 FILL_GHOST_TOP, FILL_GHOST_BOTTOM, FILL_SYNC_ONLY, FILL_NO_VERIFY = 0x10, 0x20, 0x40, 0x80
 FILL_RESUME, FILL_GHOST_GIVEN, FILL_NO_COARSE = 0x100, 0x200, 0x400
+FILL_DEFER = 0x800
 
 
 class KernelStat(ctypes.Structure):
@@ -54,7 +55,8 @@ class FillStats(ctypes.Structure):
                 ("iterations", ctypes.c_int64), ("visits_unchanged", ctypes.c_int64),
                 ("visits_requeued", ctypes.c_int64), ("round_visits", ctypes.c_int64),
                 ("pending", ctypes.c_int64), ("partial_residency", ctypes.c_int32),
-                ("flat_unchanged", ctypes.c_int32)]
+                ("flat_unchanged", ctypes.c_int32),
+                ("deferred_visits", ctypes.c_int64), ("deferred_unchanged", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -70,6 +72,8 @@ SIGNATURES = {
     "hdem_set_stream": [_vp, _vp],
     "hdem_synchronize": [_vp],
     "hdem_set_fill_slice_us": [_vp, _i],
+    "hdem_set_fill_seam_words": [_vp, _vp],
+    "hdem_fill_seam_apply_dev": [_vp, _vp, _i, _i, _vp, _vp, ctypes.c_int64, _vp],
     "hdem_set_fill_coarse_start": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_fill_hub_prepare_dev": [_vp, _vp, _i, _i, _i, _vp],
     "hdem_fill_hub_raster_dev": [_vp, _vp],
@@ -224,6 +228,17 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.hdem_synchronize(self.handle))
+
+    def set_fill_seam_words(self, dptr):
+        """Three device ints for FILL_DEFER calls (``hdem_set_fill_seam_words``); 0: none."""
+        self.check(self.lib.hdem_set_fill_seam_words(self.handle, ctypes.c_void_p(int(dptr) or None)))
+
+    def fill_seam_apply(self, w_ptr, H, W, recv_top_ptr, recv_bot_ptr, pending, words_ptr):
+        """``hdem_fill_seam_apply_dev``: received rows into the ghost rows, seam words set."""
+        vp = lambda p: ctypes.c_void_p(int(p) or None)
+        self.check(self.lib.hdem_fill_seam_apply_dev(self.handle, vp(w_ptr), int(H), int(W),
+                                                     vp(recv_top_ptr), vp(recv_bot_ptr),
+                                                     int(pending), vp(words_ptr)))
 
     def set_fill_slice_us(self, microseconds):
         """Time slice of the asynchronous sink-fill phase (0 = to convergence)."""

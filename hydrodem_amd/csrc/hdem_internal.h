@@ -71,6 +71,8 @@ struct hdem_ctx {
     const void *fill_last_z = nullptr, *fill_last_out = nullptr;
     bool fill_resumable = false;       // state words hold a consistent asynchronous worklist
     bool fill_quiescent = false;       // ... and the last call left nothing to do
+    int *fill_seam_words = nullptr;    // device: [0] queued after a deferred call, [1]/[2] ghost row changed
+    bool fill_stats_carry = false;     // deferred calls' counters are still in the workspace
     // coarse start of the sink fill: a caller's filled coarse raster for the next INIT call
     // (hdem_set_fill_coarse_start), and the buffer of the library's own coarse pre-solve
     const float *start_coarse = nullptr;

@@ -925,10 +925,12 @@ __device__ __attribute__((noinline)) flat_result flat_visit(float *wg, int H, in
 __global__ __launch_bounds__(NT) void flat_store_kernel(float *wg, int H, int W, int tiles_x,
                                                         int ntiles, const int *__restrict__ flat,
                                                         const float *__restrict__ hub_lev,
-                                                        const int *__restrict__ applied)
+                                                        const int *__restrict__ applied,
+                                                        const int *__restrict__ seam_words)
 {
     const int t = blockIdx.x;
     if (t >= ntiles) return;
+    if (seam_words && (seam_words[0] | seam_words[1] | seam_words[2]) == 0) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int lane = threadIdx.x;
     if (hub_lev && !applied[t]) {
@@ -1169,9 +1171,12 @@ __global__ __launch_bounds__(NT, 2) void fill_async_kernel(const float *__restri
                                                           long long budget_ticks, int soft,
                                                           int *flat, int *zmax,
                                                           const float *__restrict__ hub_lev,
-                                                          int *applied)
+                                                          int *applied,
+                                                          const int *__restrict__ seam_words)
 {
     __shared__ float T[WN * TS];
+    // (deferred call: no tile queued and no ghost row replaced -- known only here -- is no launch)
+    if (seam_words && (seam_words[0] | seam_words[1] | seam_words[2]) == 0) return;
     const int G = gridDim.x, b = blockIdx.x;
     const long long t_begin = wall_clock64();
     // Residency census.  The launch is sized so that every workgroup is resident at once on
@@ -1417,10 +1422,16 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
                                                       int *prio, int *pend, int stamp, int *any0,
                                                       const float *__restrict__ coarse, int cw,
                                                       int shift, const int *__restrict__ row_map,
-                                                      int W, const float *__restrict__ hub_lev)
+                                                      int W, const float *__restrict__ hub_lev,
+                                                      const int *__restrict__ seam_words)
 {
     const int t = blockIdx.x * INIT_NT + threadIdx.x;
     if (t >= tiles_x * tiles_y) return;
+    if (seam_words && mode > 0) {
+        // (deferred call: whether a ghost row was replaced is only known on the device)
+        mode &= (seam_words[1] ? HDEM_FILL_ACT_TOP : 0) | (seam_words[2] ? HDEM_FILL_ACT_BOTTOM : 0);
+        if (mode == 0) return;
+    }
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     int key = KEY_NONE;
     if (mode < 0) {
@@ -1465,10 +1476,39 @@ __global__ __launch_bounds__(INIT_NT) void fill_seed_kernel(const int *__restric
     }
 }
 
+// Counters left by deferred calls, summed into the head of the workspace (64-bit words from
+// int CARRY_INT on: visits, unchanged) before the call that reports them adds its own.
+constexpr int CARRY_INT = 8;
+__global__ __launch_bounds__(INIT_NT) void fill_carry_sum_kernel(const unsigned long long *__restrict__ stats,
+                                                                 int G, int *__restrict__ head)
+{
+    unsigned long long v = 0, u = 0;
+    for (int b = threadIdx.x; b < G; b += INIT_NT) {
+        v += stats[(size_t)b * STAT_WORDS + 0];
+        u += stats[(size_t)b * STAT_WORDS + 2];
+    }
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(head + CARRY_INT);
+    if (v) atomicAdd(out, v);
+    if (u) atomicAdd(out + 1, u);
+}
+
+// Behind a deferred launch: words[0] <- are tiles still queued (or did the launch give up)?
+__global__ __launch_bounds__(NT) void fill_seam_busy_kernel(const int *__restrict__ pend,
+                                                            const int *__restrict__ error,
+                                                            int *__restrict__ words)
+{
+    int p = pend[threadIdx.x * PEND_STRIDE];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) p += __shfl_xor(p, o);
+    if (threadIdx.x == 0) words[0] = (p > 0 || error[0] != 0) ? 1 : 0;
+}
+
 size_t stat_ints_of(const fill_ws &ws) { return (size_t)ws.G * STAT_WORDS * 2; }
 
-int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, fill_ws *ws)
+int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, fill_ws *ws,
+              bool *keep_stats_io = nullptr)
 {
+    bool keep_stats = keep_stats_io && *keep_stats_io;
     // tiles cover the interior (rows 1..H-2, cols 1..W-2); none if there is no interior
     ws->tiles_x = W >= 3 && H >= 3 ? (W - 2 + FT - 1) / FT : 0;
     ws->tiles_y = W >= 3 && H >= 3 ? (H - 2 + FT - 1) / FT : 0;
@@ -1496,9 +1536,10 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
         if (int rc = hdem_raw_alloc(ctx, bytes, &ws_buf)) return rc;
         ws_bytes = bytes;
         *resume = false;                                           // the worklist went with it
+        keep_stats = false;                                        // (and the counters)
     }
-    const size_t host_ints = std::max(std::max(head + stat_ints, (size_t)max_rounds + 32),
-                                       (size_t)PEND_SHARDS * PEND_STRIDE);
+    const size_t host_ints = std::max(head + stat_ints + (size_t)PEND_SHARDS * PEND_STRIDE,
+                                       (size_t)max_rounds + 32);
     if (ctx->host_counts_len < host_ints) {
         if (ctx->host_counts) HDEM_HIP_CHECK(hipHostFree(ctx->host_counts));
         ctx->host_counts = nullptr;
@@ -1524,7 +1565,15 @@ int ensure_ws(hdem_ctx *ctx, int H, int W, int max_rounds, int G, bool *resume, 
     // launch and are written out behind it); a resumed worklist keeps pend / state /
     // tile_key / prio of the last slice
     const size_t zeros = head + stat_ints + any_ints + n + (*resume ? 0 : pend_ints + gs);
-    HDEM_HIP_CHECK(hipMemsetAsync(base, 0, zeros * sizeof(int), ctx->stream));
+    if (keep_stats_io) *keep_stats_io = keep_stats;
+    if (keep_stats) {
+        // (the counters of deferred calls stay: the first call that waits reports them too)
+        HDEM_HIP_CHECK(hipMemsetAsync(base, 0, head * sizeof(int), ctx->stream));
+        HDEM_HIP_CHECK(hipMemsetAsync(base + head + stat_ints, 0,
+                                      (zeros - head - stat_ints) * sizeof(int), ctx->stream));
+    } else {
+        HDEM_HIP_CHECK(hipMemsetAsync(base, 0, zeros * sizeof(int), ctx->stream));
+    }
     int *sevens = *resume ? ws->flat : ws->tile_key;
     HDEM_HIP_CHECK(hipMemsetAsync(sevens, 0x7f, (size_t)(ws->zmax + n - sevens) * sizeof(int),
                                   ctx->stream));
@@ -1664,6 +1713,60 @@ extern "C" int hdem_set_fill_hub_levels(hdem_ctx *ctx, const float *levels)
     HDEM_REQUIRE(!levels || ctx->hub_prep_z, HDEM_ERR_BAD_ARG,
                  "no prepared hub start (hdem_fill_hub_prepare_dev)");
     ctx->hub_levels_given = levels;
+    return HDEM_OK;
+}
+
+// One seam exchange's bookkeeping in one launch: the received rows replace the ghost rows;
+// words[1] / words[2] <- the top / bottom ghost row got different bits (NaN included: bit
+// patterns, not values); words[3] <- any of words[0..2] (what the ranks vote on).
+__global__ __launch_bounds__(INIT_NT) void fill_seam_apply_kernel(float *__restrict__ w, int H, int W,
+                                                                  const float *__restrict__ recv_top,
+                                                                  const float *__restrict__ recv_bot,
+                                                                  int pending, int *__restrict__ words)
+{
+    const int x = blockIdx.x * INIT_NT + threadIdx.x;
+    if (x == 0) {
+        const int p = pending >= 0 ? (pending > 0) : (words[0] != 0);
+        words[0] = p;
+        if (p) atomicMax(words + 3, 1);
+    }
+    if (x >= W) return;
+    int *wi = reinterpret_cast<int *>(w);
+    bool top = false, bot = false;
+    if (recv_top) {
+        const int v = reinterpret_cast<const int *>(recv_top)[x];
+        top = v != wi[x];
+        wi[x] = v;
+    }
+    if (recv_bot) {
+        const size_t o = (size_t)(H - 1) * W + x;
+        const int v = reinterpret_cast<const int *>(recv_bot)[x];
+        bot = v != wi[o];
+        wi[o] = v;
+    }
+    if (__any(top)) { if ((threadIdx.x & 63) == 0) { atomicMax(words + 1, 1); atomicMax(words + 3, 1); } }
+    if (__any(bot)) { if ((threadIdx.x & 63) == 0) { atomicMax(words + 2, 1); atomicMax(words + 3, 1); } }
+}
+
+extern "C" int hdem_fill_seam_apply_dev(hdem_ctx *ctx, float *w, int H, int W,
+                                        const float *recv_top, const float *recv_bot,
+                                        int64_t pending, int *words)
+{
+    HDEM_REQUIRE(ctx && w && words, HDEM_ERR_BAD_ARG, "null argument");
+    HDEM_REQUIRE(H >= 1 && W >= 1, HDEM_ERR_BAD_ARG, "bad shape %d x %d", H, W);
+    HDEM_HIP_CHECK(hipSetDevice(ctx->device));
+    HDEM_HIP_CHECK(hipMemsetAsync(words + 1, 0, 3 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(fill_seam_apply_kernel, dim3((W + INIT_NT - 1) / INIT_NT), dim3(INIT_NT), 0,
+                       ctx->stream, w, H, W, recv_top, recv_bot,
+                       pending < 0 ? -1 : (pending > 0 ? 1 : 0), words);
+    HDEM_HIP_CHECK(hipGetLastError());
+    return HDEM_OK;
+}
+
+extern "C" int hdem_set_fill_seam_words(hdem_ctx *ctx, int *words)
+{
+    HDEM_REQUIRE(ctx, HDEM_ERR_BAD_ARG, "ctx is null");
+    ctx->fill_seam_words = words;
     return HDEM_OK;
 }
 
@@ -1810,9 +1913,19 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // (HDEM_FILL_WGS_PER_CU: experiments and tests; the machine holds 8 of these one-wave
     // workgroups per CU -- more than 8 is a launch that cannot be resident at once)
     const int wgs_per_cu = getenv("HDEM_FILL_WGS_PER_CU") ? atoi(getenv("HDEM_FILL_WGS_PER_CU")) : 8;
+    bool keep_stats = ctx->fill_stats_carry && same && !ctx->in_coarse_presolve;
     if (int rc = ensure_ws(ctx, H, W, max_rounds, ctx->num_cus * std::max(1, std::min(wgs_per_cu, 16)),
-                           &resume, &ws))
+                           &resume, &ws, &keep_stats))
         return rc;
+    if (!ctx->in_coarse_presolve) ctx->fill_stats_carry = false;
+    if (keep_stats && !(flags & HDEM_FILL_DEFER))
+        hipLaunchKernelGGL(fill_carry_sum_kernel, dim3(1), dim3(INIT_NT), 0, ctx->stream, ws.stats,
+                           ws.G, ws.error);
+    // a deferred call (see the header): only as a resumed correcting solve
+    const bool defer = (flags & HDEM_FILL_DEFER) != 0;
+    HDEM_REQUIRE(!defer || (want_resume && use_async && ctx->fill_seam_words && !d8_request),
+                 HDEM_ERR_BAD_ARG,
+                 "HDEM_FILL_DEFER needs WARM | RESUME, seam words and the asynchronous driver");
     // not resumable: fine if the last call on this problem left nothing queued (then the ACT
     // flags describe all there is to do), otherwise every tile is due again
     if (want_resume && !resume && !(same && ctx->fill_quiescent))
@@ -1831,6 +1944,8 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
     // resuming with no replaced ghost row: nothing to add to the worklist (mode 0 would
     // mean "all tiles")
     const bool seed_async = !(resume && mode == 0);
+    // (a deferred call whose words are all clear has nothing to do -- unless every tile is due)
+    const int *idle_words = (defer && mode != 0) ? ctx->fill_seam_words : nullptr;
     const int slice_us = (flags & HDEM_FILL_NO_VERIFY) ? ctx->fill_slice_us : 0;
     int64_t pending = 0;
 
@@ -1882,7 +1997,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                                ws.tile_key, ws.tiles_x, ws.tiles_y, H, mode, ws.G, ws.S, 1,
                                ws.state, ws.prio, ws.pend, 0, ws.any, coarse, coarse_cw,
-                               coarse_shift, row_map, W, hub_lev);
+                               coarse_shift, row_map, W, hub_lev, defer ? ctx->fill_seam_words : nullptr);
         // wall-clock budget (100 MHz ticks): generous against the ~0.15 us per tile a
         // 16384^2 fill takes, small enough that a stuck launch costs a fraction of a second;
         // or the caller's time slice (soft: the launch just stops taking tiles)
@@ -1900,23 +2015,23 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
             hipLaunchKernelGGL((fill_async_kernel<true, 0>), dim3(ws.G), dim3(NT), 0, st, z, w, H,
                                W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
                                ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
-                               hub_lev, ws.applied);
+                               hub_lev, ws.applied, idle_words);
         else if (ctx->in_coarse_presolve)
             hipLaunchKernelGGL((fill_async_kernel<false, 1>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
                                ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
-                               hub_lev, ws.applied);
+                               hub_lev, ws.applied, idle_words);
         else
             hipLaunchKernelGGL((fill_async_kernel<false, 0>), dim3(ws.G), dim3(NT), 0, st, z, w,
                                H, W, eps, ws.tiles_x, ws.tiles_y, ws.ntiles, ws.S, ws.state,
                                ws.prio, ws.pend, ws.error, ws.stats, budget, soft, ws.flat, ws.zmax,
-                               hub_lev, ws.applied);
+                               hub_lev, ws.applied, idle_words);
     }
     if (did_async && eps == 0.0f) {
         // tiles that ended the launch flat have only their edge lines in memory
         hdem_scoped_timer tm(ctx, HDEM_K_FILL_FLAT, 0);
         hipLaunchKernelGGL(flat_store_kernel, dim3(ws.ntiles), dim3(NT), 0, st, w, H, W, ws.tiles_x,
-                           ws.ntiles, ws.flat, hub_lev, ws.applied);
+                           ws.ntiles, ws.flat, hub_lev, ws.applied, idle_words);
     }
     HDEM_HIP_CHECK(hipGetLastError());
     // ---- round-synchronous phase: certifies (or finishes) the fixed point --------
@@ -1933,19 +2048,34 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         ctx->fill_resumable = ctx->fill_quiescent = false;
         return HDEM_OK;
     }
+    if (defer && did_async && !verify) {
+        hipLaunchKernelGGL(fill_seam_busy_kernel, dim3(1), dim3(NT), 0, st, ws.pend, ws.error,
+                           ctx->fill_seam_words);
+        HDEM_HIP_CHECK(hipGetLastError());
+        if (stats) { *stats = hdem_fill_stats{}; stats->pending = -1; stats->tiles = ws.ntiles; stats->tile_h = stats->tile_w = FT; }
+        ctx->fill_stats_carry = true;
+        ctx->fill_resumable = true;          // (the worklist is whatever the launch leaves)
+        ctx->fill_quiescent = false;
+        return HDEM_OK;
+    }
     if (!verify) {
         // trust the asynchronous phase unless it gave up; after a time slice, report how
         // many tiles are still queued (the worklist stays in the workspace for RESUME)
-        HDEM_HIP_CHECK(hipMemcpyAsync(&async_error, ws.error, sizeof(int), hipMemcpyDeviceToHost, st));
+        // (one wait for all of it: head words, counters and -- after a slice -- the shards of
+        // the pending count, which sit behind the counters' neighbours in the workspace)
+        HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.error,
+                                      (HEAD_INTS + stat_ints_of(ws)) * sizeof(int),
+                                      hipMemcpyDeviceToHost, st));
+        int *host_pend = ctx->host_counts + HEAD_INTS + stat_ints_of(ws);
         if (slice_us > 0)
-            HDEM_HIP_CHECK(hipMemcpyAsync(ctx->host_counts, ws.pend,
-                                          PEND_SHARDS * PEND_STRIDE * sizeof(int),
+            HDEM_HIP_CHECK(hipMemcpyAsync(host_pend, ws.pend, PEND_SHARDS * PEND_STRIDE * sizeof(int),
                                           hipMemcpyDeviceToHost, st));
         HDEM_HIP_CHECK(hipStreamSynchronize(st));
+        async_error = ctx->host_counts[0];
         if (slice_us > 0)
-            for (int i = 0; i < PEND_SHARDS; ++i) pending += ctx->host_counts[i * PEND_STRIDE];
+            for (int i = 0; i < PEND_SHARDS; ++i) pending += host_pend[i * PEND_STRIDE];
         if (async_error) { verify = true; pending = 0; }
-        else converged = pending == 0;
+        else { converged = pending == 0; have_counts = true; }
     }
     // (the pass must see every tile: behind the asynchronous phase, or a WARM round-driver
     // call with all tiles due -- the verifying call of the row-block loop)
@@ -1974,7 +2104,7 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         hipLaunchKernelGGL(fill_seed_kernel, dim3(tile_blocks), dim3(INIT_NT), 0, st,
                            ws.tile_key, ws.tiles_x, ws.tiles_y, H, did_async ? 0 : mode, ws.G,
                            ws.S, 0, ws.state, ws.prio, ws.pend, (int)ST_ROUND0, ws.any, nullptr, 0,
-                           0, nullptr, W, nullptr);
+                           0, nullptr, W, nullptr, nullptr);
     // rounds per host check: behind the asynchronous phase the first round is expected to
     // find nothing, so only one more is queued with it (an empty launch costs ~9 us)
     const int KB = did_async ? 2 : K;
@@ -2047,7 +2177,12 @@ extern "C" int hdem_sinkfill_f32_dev(hdem_ctx *ctx, const float *z, int H, int W
         stats->visits_requeued = (int64_t)tot[3];
         stats->round_visits = (int64_t)tot[6];
     }
-    if (stats) stats->pending = pending;
+    if (stats) {
+        stats->pending = pending;
+        const unsigned long long *carry = (const unsigned long long *)(ctx->host_counts + CARRY_INT);
+        stats->deferred_visits = (int64_t)carry[0];
+        stats->deferred_unchanged = (int64_t)carry[1];
+    }
     if (!converged && pending == 0) {
         hdem_set_error("sink fill did not converge in %d rounds", max_rounds);
         return HDEM_ERR_NOT_CONVERGED;

@@ -45,6 +45,7 @@ tests pass a NumPy solver so that this exchange logic runs under ``gloo``.
 """
 
 import contextlib
+import os
 import time
 
 import numpy as np
@@ -164,7 +165,36 @@ class HipLocalSolver:
             finally:
                 self.ctx.set_fill_slice_us(0)
         self.last_stats = st
-        return st["tile_visits"], st["tile_visits"] > st["visits_unchanged"], st["pending"]
+        # (counters of deferred solves before this call ride along: not this call's lowering)
+        own = st["tile_visits"] - st.get("deferred_visits", 0)
+        own_same = st["visits_unchanged"] - st.get("deferred_unchanged", 0)
+        return st["tile_visits"], own > own_same, st["pending"]
+
+    # the correcting solves of the exchange loop can be enqueued without a host wait
+    can_defer = True
+
+    def fill_deferred(self, z, w, eps, flags, words):
+        """Enqueue a correcting solve (``FILL_WARM | FILL_RESUME`` + ACT bits) and return
+        without waiting: ``words`` (int32[3], device) carries what the solve needs to know and
+        what it has to tell -- ``hdem_set_fill_seam_words``.  Its counters arrive with the next
+        :meth:`fill` (``deferred_visits``)."""
+        with self._call("fill_deferred"):
+            self.ctx.set_fill_slice_us(self.slice_us)
+            self.ctx.set_fill_seam_words(words.data_ptr())
+            try:
+                backend.sinkfill_dev(self._wrap(z, np.float32), eps=eps,
+                                     out=self._wrap(w, np.float32),
+                                     flags=flags | backend.FILL_DEFER)
+            finally:
+                self.ctx.set_fill_slice_us(0)
+                self.ctx.set_fill_seam_words(0)
+
+    def seam_apply(self, w, recv_top, recv_bot, pending, words):
+        """Received rows into the ghost rows of ``w``, seam words set -- one launch."""
+        ptr = lambda t: 0 if t is None else t.data_ptr()
+        with self._call("seam"):
+            self.ctx.fill_seam_apply(w.data_ptr(), w.shape[0], w.shape[1], ptr(recv_top),
+                                     ptr(recv_bot), pending, words.data_ptr())
 
     def set_coarse_start(self, filled, block, row_map):
         """Start values of the next INIT ``fill``: device tensors, see
@@ -386,7 +416,13 @@ class _Seam:
         row = lambda: torch.empty(w.shape[1], dtype=w.dtype, device=w.device)
         self.recv_top = row() if top else None
         self.recv_bot = row() if bottom else None
-        self.word = torch.zeros(3, dtype=torch.int32, device=w.device)   # busy, top, bottom
+        # busy, top, bottom (+ deferred loop: any of the three, the word that is voted on)
+        self.word = torch.zeros(4, dtype=torch.int32, device=w.device)
+        # deferred loop: the vote's copy on the host and the event that says it has arrived
+        self.vote_host = self.event = None
+        if w.is_cuda:
+            self.vote_host = torch.zeros(1, dtype=torch.int32, device="cpu", pin_memory=True)
+            self.event = torch.cuda.Event()
 
 
 def _exchange_and_vote(comm, torch, w, top, bottom, pending, seam, ghost=1):
@@ -398,7 +434,7 @@ def _exchange_and_vote(comm, torch, w, top, bottom, pending, seam, ghost=1):
     # the row rank-1 pins is `ghost` rows into my block: index 2 * ghost - 1 here
     comm.swap(w[2 * ghost - 1] if top else None, w[h - 2 * ghost] if bottom else None,
               seam.recv_top, seam.recv_bot)
-    word = seam.word
+    word = seam.word[:3]
     word.zero_()
     if top:
         word[1] = (seam.recv_top.view(torch.int32) != w[0].view(torch.int32)).any()
@@ -410,6 +446,21 @@ def _exchange_and_vote(comm, torch, w, top, bottom, pending, seam, ghost=1):
     busy = comm.all_reduce_max(word[:1].clone())
     out = torch.cat([busy, word[1:]]).cpu()                         # the one read-back
     return bool(out[0]), bool(out[1]), bool(out[2])
+
+
+def _exchange_and_vote_deferred(comm, solver, w, top, bottom, pending, seam, ghost=1):
+    """The same exchange and vote with every answer left on the device: the ghost-changed
+    words stay in ``seam.word[1:]`` for the deferred solve that follows (its seeding reads them),
+    the vote is copied to pinned host memory behind the all-reduce and ``seam.event`` marks its
+    arrival -- the caller enqueues the next solve first and looks at the vote afterwards.
+    ``pending`` < 0: ``seam.word[0]`` already holds what the last deferred solve left queued."""
+    h = w.shape[0]
+    comm.swap(w[2 * ghost - 1] if top else None, w[h - 2 * ghost] if bottom else None,
+              seam.recv_top, seam.recv_bot)
+    solver.seam_apply(w, seam.recv_top, seam.recv_bot, pending, seam.word)
+    busy = comm.all_reduce_max(seam.word[3:])
+    seam.vote_host.copy_(busy, non_blocking=True)
+    seam.event.record()
 
 
 def coarse_start(z_local, comm, solver, block=COARSE_BLOCK, ghost=1):
@@ -608,9 +659,27 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     del keep                                       # (alive until the solve has consumed them)
     exchanges = verifications = 0
     seam = _Seam(torch, w, top, bottom) if world > 1 else None
+    # Deferred loop (device solvers): no host decision stands between a seam exchange and the
+    # correcting solve behind it.  The solve is enqueued at once -- seeded on the device from the
+    # ghost-changed words, a no-op when they are clear and nothing is queued -- and the vote is
+    # looked at while it runs; a vote of "all at rest" means that solve found nothing to do.
+    defer = world > 1 and w.is_cuda and getattr(solver, "can_defer", False) and \
+        os.environ.get("HDEM_PARTITION_DEFER", "1") != "0"
+    tally["deferred"] = 0
     while world > 1:
-        any_busy, ch_top, ch_bot = _exchange_and_vote(comm, torch, w, top, bottom, pending,
-                                                      seam, ghost)
+        if defer:
+            _exchange_and_vote_deferred(comm, solver, w, top, bottom, pending, seam, ghost)
+            act = backend.FILL_WARM | backend.FILL_RESUME | backend.FILL_NO_VERIFY
+            act |= backend.FILL_ACT_TOP if top else 0
+            act |= backend.FILL_ACT_BOTTOM if bottom else 0
+            solver.fill_deferred(z_local, w, eps, act, seam.word)
+            tally["deferred"] += 1
+            pending = -1                               # (on the device: seam.word[0])
+            seam.event.synchronize()
+            any_busy, ch_top, ch_bot = bool(seam.vote_host[0]), False, False
+        else:
+            any_busy, ch_top, ch_bot = _exchange_and_vote(comm, torch, w, top, bottom, pending,
+                                                          seam, ghost)
         exchanges += 1
         if exchanges >= max_exchanges:
             raise RuntimeError("distributed sink fill did not converge")
@@ -623,8 +692,9 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             seam.word[0] = int(lowered)
             if int(comm.all_reduce_max(seam.word[:1].clone()).item()) == 0:
                 break
+            pending = 0                                # (the round driver leaves nothing queued)
             continue
-        if ch_top or ch_bot or pending > 0:
+        if not defer and (ch_top or ch_bot or pending > 0):
             # next slice: the tiles left queued plus those next to a replaced ghost row
             act = backend.FILL_WARM | backend.FILL_RESUME | backend.FILL_NO_VERIFY
             act |= backend.FILL_ACT_TOP if ch_top else 0
@@ -635,7 +705,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     return w, {"tile_visits": tally["tile_visits"], "visits_unchanged": tally["unchanged"],
                "exchanges": exchanges, "verifications": verifications,
                "solves": tally["solves"], "async_fallbacks": tally["fallbacks"],
-               "shared_gpu_solves": tally["shared"], "start_values": tally["start"]}
+               "shared_gpu_solves": tally["shared"], "start_values": tally["start"],
+               "deferred_solves": tally["deferred"]}
 
 
 def d8_distributed(w_local, solver, out=None):

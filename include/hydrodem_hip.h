@@ -151,6 +151,8 @@ typedef struct hdem_fill_stats {
                                  started without them and took their tiles       */
     int32_t flat_unchanged;   /* of visits_flat: those that found nothing to lower (they are
                                  part of visits_unchanged as well)               */
+    int64_t deferred_visits;  /* of tile_visits / visits_unchanged: made by HDEM_FILL_DEFER  */
+    int64_t deferred_unchanged; /* calls before this one, which is the first to report them */
 } hdem_fill_stats;
 
 #define HDEM_FILL_INIT        0x0  /* w is output only: pinned ring <- z, rest from above */
@@ -180,6 +182,13 @@ typedef struct hdem_fill_stats {
                                       caller's guess, e.g. from a coarse solve): start from
                                       those instead of +inf.  Must be >= the true fill.    */
 
+#define HDEM_FILL_DEFER       0x800 /* WARM | RESUME: enqueue the solve and return without
+                                      waiting for it and without reading anything back: for the
+                                      correcting solves of a halo-exchange loop that keeps its
+                                      decisions on the device (hdem_set_fill_seam_words).  The
+                                      call's counters are added to those of the next call on this
+                                      problem that does wait; stats->pending is -1.          */
+
 /* eps = 0 gives flats (exact, order-independent, bit-reproducible);
  * eps > 0 is the Planchon-Darboux gradient.  max_rounds <= 0 -> default. */
 int hdem_sinkfill_f32(hdem_ctx *ctx, const float *z, int H, int W, float eps,
@@ -201,6 +210,23 @@ int hdem_sinkfill_d8_f32_dev(hdem_ctx *ctx, const float *z, int H, int W, float 
  * HDEM_FILL_WARM | HDEM_FILL_RESUME.  This is what lets row blocks on different
  * GPUs trade ghost rows every millisecond instead of once per local convergence. */
 int hdem_set_fill_slice_us(hdem_ctx *ctx, int microseconds);
+/* Seam words of a halo-exchange loop that does not come back to the host between a seam
+ * exchange and the solve behind it (new work; partition.py).  `words`: three ints in
+ * device memory, owned by the caller, valid until the next call replaces them (NULL: none):
+ *   words[1], words[2]   written by the caller on the stream before a HDEM_FILL_DEFER call:
+ *                        non-zero = ghost row 0 / H-1 was replaced by different values.  The
+ *                        call's HDEM_FILL_ACT_TOP / ACT_BOTTOM then only act when the word is set;
+ *   words[0]             written by every HDEM_FILL_DEFER call, on the stream, when its launch has
+ *                        ended: 1 = tiles are still queued (a time slice ended first), else 0.
+ * The words are read and written by kernels on the context's stream, never by the host. */
+int hdem_set_fill_seam_words(hdem_ctx *ctx, int *words);
+/* The bookkeeping of one seam exchange as one launch on the context's stream (device pointers):
+ * recv_top / recv_bot (W floats each, NULL: no such neighbour) replace row 0 / row H-1 of w;
+ * words[1] / words[2] <- that row's bits changed; words[0] <- pending > 0 when pending >= 0
+ * (pending < 0: words[0] is what the last deferred call left there); words[3] <- any of
+ * words[0..2], the word the ranks MAX-reduce.  `words`: four ints, the first three as above. */
+int hdem_fill_seam_apply_dev(hdem_ctx *ctx, float *w, int H, int W, const float *recv_top,
+                             const float *recv_bot, int64_t pending, int *words);
 
 /* Hub start of a row-block partition (new work; no reference counterpart -- SURVEY 8e).  The
  * single-GPU fill starts from a graph of tile hubs (one hub per 62 x 62 tile, path costs d to

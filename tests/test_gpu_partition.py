@@ -193,3 +193,49 @@ def test_partition_hub_start_bounds_the_fill(built, world, rows, cols, holes):
     got = P.ThreadWorld(world).run(body)
     assert [g[0] for g in got] == [0] * world, f"start values below the fill: {got}"
     assert min(g[1] for g in got) > 0.3             # and tight: a third of the cells exact
+
+
+@pytest.mark.parametrize("world,rows,cols,holes,hub", [(4, 640, 1500, False, True),
+                                                       (3, 500, 900, True, False)])
+def test_partition_deferred_loop_matches_the_waiting_one(built, monkeypatch, world, rows, cols,
+                                                         holes, hub):
+    """The exchange loop that keeps its decisions on the device (HDEM_FILL_DEFER: seam words,
+    solves enqueued without a host wait, vote looked at behind them) against the loop that
+    reads every vote back first: same bits as the C oracle from both, on every rank, and the
+    counters of the deferred solves arrive with the verifying call.  Starts far from the truth
+    (hub = False: +inf ghost rows) so that several exchanges really correct something."""
+    from hydrodem_amd import partition as P
+    h = world * rows
+    z = oracle.synth_dem(h, cols, variant="rough")
+    if holes:
+        z[rows - 9:rows + 12, 200:260] = np.nan
+    want = c_oracle.sinkfill_pflood(z)
+    ghost = P.ghost_rows(world, h)
+
+    def run(defer):
+        monkeypatch.setenv("HDEM_PARTITION_DEFER", "1" if defer else "0")
+
+        def body(rank, comm):
+            g0, g1, _, _ = P.local_range(rank, world, h, ghost)
+            zt = torch.from_numpy(z[g0:g1]).cuda()
+            solver = P.HipLocalSolver(0, turn=comm.gpu_turn)
+            w, info = P.sinkfill_distributed(zt, rank, world, solver, ghost=ghost, comm=comm,
+                                             hub=hub, coarse_block=0)
+            out = w.cpu().numpy()
+            solver.ctx.close()
+            return out, info, (g0, g1)
+
+        return P.ThreadWorld(world).run(body)
+
+    for defer in (True, False):
+        got = run(defer)
+        for w, info, (g0, g1) in got:
+            assert np.array_equal(w, want[g0:g1], equal_nan=True), (defer, info)
+            assert (info["deferred_solves"] > 0) == defer
+            assert info["deferred_solves"] in (0, info["exchanges"])
+        if defer:
+            # every rank's tally holds the visits of its deferred solves (reported by the
+            # verifying call): more than the first solve and the verifying passes alone
+            for _, info, _ in got:
+                first = info["solves"][0][1]
+                assert info["tile_visits"] >= first

@@ -196,7 +196,7 @@ def test_python_constants_match_the_header():
     assert int(enums["HDEM_ERR_NOT_CONVERGED"]) == backend.NOT_CONVERGED
     # struct layouts the binding mirrors
     # struct layouts the binding mirrors: 6 int32 + 6 int64 + 2 int32 / 2 int64 + 1 double
-    assert ctypes.sizeof(backend.FillStats) == 88 and backend.FillStats.pending.offset == 72
+    assert ctypes.sizeof(backend.FillStats) == 104 and backend.FillStats.pending.offset == 72
     assert backend.FillStats.partial_residency.offset == 80
     assert ctypes.sizeof(backend.KernelStat) == 24
 
