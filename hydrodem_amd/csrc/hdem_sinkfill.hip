@@ -136,6 +136,15 @@ __device__ __forceinline__ void or_less(unsigned long long &acc, float a, float 
 
 // bit `shift` of west / east |= (a < b) in lane 0 / lane 63.  One block, so that the compare
 // mask is consumed at once (see or_changed).
+// acc <- 2 acc + (a < b), per lane: a shift register of compare results that costs two vector
+// instructions per step and no scalar one (the carry-in of v_addc is the compare's mask).
+__device__ __forceinline__ void shift_in_less(unsigned &acc, float a, float b)
+{
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\t"
+                 "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+                 : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+
 __device__ __forceinline__ void column_bits(unsigned &west, unsigned &east, float a, float b,
                                             int shift)
 {
@@ -322,18 +331,32 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         wbase, 0, COHERENT ? (int)(unsigned)(wbytes < 0xffffffffull ? wbytes : 0xffffffffull) : 0,
         0x00020000);
+    // window row of the raster's last row (uniform; >= 63 unless the window overhangs)
+    const int hbrow = H - 1 - y0;
+    if (COHERENT) {
+        // Z through a resource based at the same row: one scalar row offset (s_min, s_mul) serves
+        // both loads of a row and the lane's column offset is one register for all 128 -- the
+        // 64-bit address arithmetic of 64 global loads was 300 scalar instructions per visit
+        const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(zg) + (size_t)y0 * W, 0,
+            (int)(unsigned)(wbytes < 0xffffffffull ? wbytes : 0xffffffffull), 0x00020000);
+        const unsigned col = (unsigned)xc * (unsigned)sizeof(float);
+        const unsigned pitch = (unsigned)W * (unsigned)sizeof(float);
 #pragma unroll
-    for (int r = 0; r < WN; ++r) {
-        const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
-        z[r] = zg[o];
-        // (an agent-scope __hip_atomic_load is waited for one by one -- 64 serial round
-        // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
-        if (COHERENT)
-            w[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                wrsrc, (unsigned)(((size_t)(min(y0 + r, H - 1) - y0) * W + xc) * sizeof(float)), 0,
-                AUX_SC1));
-        else
+        for (int r = 0; r < WN; ++r) {
+            const unsigned row = (unsigned)min(r, hbrow) * pitch;
+            z[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrsrc, col, row, 0));
+            // (an agent-scope __hip_atomic_load is waited for one by one -- 64 serial round
+            // trips; a buffer load with the sc1 bit is an ordinary, pipelined load)
+            w[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, col, row, AUX_SC1));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            const size_t o = (size_t)min(y0 + r, H - 1) * W + xc;
+            z[r] = zg[o];
             w[r] = wg[o];
+        }
     }
     // Normalise: nodata (NaN) becomes the wall +inf in both arrays (fminf returns the
     // operand that is a number), cells outside the raster likewise, and the cells that
@@ -352,7 +375,7 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
     // the load saves another 3 % of the visits but puts 8 loads on the path to the
     // hand-off: 6.2 against 5.9 ms.)
     unsigned long long free_n = ~0ull, free_s = ~0ull;
-    unsigned fw_lo = 0, fw_hi = 0, fe_lo = 0, fe_hi = 0;
+    unsigned free_lo = 0, free_hi = 0;          // per lane: bit 31 - r of lo / hi <- row r / 32 + r free
     // (hub start) cells of tiles that have not had their first visit still hold d: raise them
     // to their tile's start bound -- per lane the bound of the tile above / beside / below
     float hub_t = -HDEM_INF, hub_m = -HDEM_INF, hub_b = -HDEM_INF;
@@ -362,32 +385,46 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         hub_m = k == 0 ? hb->lv[3] : (k == 1 ? hb->lv[4] : hb->lv[5]);
         hub_b = k == 0 ? hb->lv[6] : (k == 1 ? hb->lv[7] : hb->lv[8]);
     }
+    // What depends on the row is decided per lane against a row number held in a register --
+    // one vector compare with the row as a literal -- not per row in scalar code: the uniform
+    // form cost ten scalar instructions per row (compare, select, combine the masks), 640 per
+    // visit, for conditions that only the raster's last tiles ever meet.
+    //   pin_from: rows from here on are pinned in this lane (pinned lane: all; else the raster's
+    //             last row and what lies beyond it -- copies of that row, see the loads)
+    //   raise_to: the hub bound applies to rows below this one (tile interiors only: on the
+    //             raster's last tiles the window also holds the raster ring, which is the
+    //             boundary condition, not a start value)
+    const int pin_from = lane_pin ? 0 : min(hbrow, WN - 1);
+    const int raise_to = x >= W - 1 ? 0 : min(hbrow, WN);
 #pragma unroll
     for (int r = 0; r < WN; ++r) {
-        const int y = y0 + r;
         float wc = fminf(w[r], HDEM_INF), zc = fminf(z[r], HDEM_INF);
-        if (COHERENT && hb) {
-            // (tile interiors only: on the raster's last tiles the window also holds the
-            // raster ring, which is the boundary condition, not a start value)
-            float bound = r == 0 ? hub_t : (r == WN - 1 ? hub_b : hub_m);
-            if (partial && (x >= W - 1 || y >= H - 1)) bound = -HDEM_INF;
-            wc = fmaxf(wc, bound);
+        if (COHERENT) {
+            const float bound = r == 0 ? hub_t : (r == WN - 1 ? hub_b : hub_m);
+            wc = fmaxf(wc, r < raise_to ? bound : -HDEM_INF);
         }
-        if (partial && (lane_out || y >= H)) { wc = HDEM_INF; zc = HDEM_INF; }
+        if (!COHERENT && partial && (lane_out || y0 + r >= H)) { wc = HDEM_INF; zc = HDEM_INF; }
         if (COHERENT) {
             // rows 0 / 63: the halo rows, one bit per lane; every row: its two halo-column
-            // cells sit in lanes 0 and 63 right now -- their bits go to row r of two
-            // lane = row masks (one compare and six scalar operations; no second, strided
-            // fetch of Z later)
+            // cells sit in lanes 0 and 63 right now -- every lane shifts its own compare into a
+            // register (two vector instructions, no scalar one) and lanes 0 and 63 are read
+            // out after the loop: no second, strided fetch of Z later
             if (r == 0) free_n = __ballot(zc < wc);
             if (r == WN - 1) free_s = __ballot(zc < wc);
-            if (r < 32) column_bits(fw_lo, fe_lo, zc, wc, r);
-            else column_bits(fw_hi, fe_hi, zc, wc, r - 32);
+            if (r < 32) shift_in_less(free_lo, zc, wc);
+            else shift_in_less(free_hi, zc, wc);
         }
-        const bool row_pin = r == 0 || r == WN - 1 || y == 0 || y >= H - 1;   // uniform
         // (a pinned nodata cell has w = NaN -> +inf as well, so z = w is the wall there too)
-        z[r] = (row_pin || lane_pin) ? wc : zc;
+        z[r] = (r == 0 || r == WN - 1 || r >= pin_from) ? wc : zc;
         w[r] = wc;
+    }
+    if (COHERENT && partial) {
+        // Cells beyond the raster are copies of its ring (clamped loads), pinned like it: nothing
+        // inside the tile can see them past the ring.  They must not count as halo cells that
+        // a new edge could lower, though -- their bits leave the masks here, once.
+        const unsigned long long in_lanes = __ballot(!lane_out);
+        free_n &= in_lanes;
+        free_s = hbrow >= WN - 1 ? (free_s & in_lanes) : 0ull;
     }
 
     if (COHERENT && flat_level < HDEM_INF) {
@@ -398,8 +435,19 @@ __device__ __forceinline__ visit_result tile_visit(const float *__restrict__ zg,
         for (int r = 2; r <= FT - 1; ++r) w[r] = inner_lane ? flat_level : w[r];
     }
 
-    const unsigned long long free_w = ((unsigned long long)fw_hi << 32) | fw_lo;
-    const unsigned long long free_e = ((unsigned long long)fe_hi << 32) | fe_lo;
+    // the halo columns are lanes 0 and 63: their registers, bit-reversed, are lane = row masks
+    unsigned long long free_w = 0, free_e = 0;
+    if (COHERENT) {
+        const unsigned wl = __builtin_amdgcn_readlane(free_lo, 0), wh = __builtin_amdgcn_readlane(free_hi, 0);
+        const unsigned el = __builtin_amdgcn_readlane(free_lo, WN - 1), eh = __builtin_amdgcn_readlane(free_hi, WN - 1);
+        free_w = ((unsigned long long)__builtin_bitreverse32(wh) << 32) | __builtin_bitreverse32(wl);
+        free_e = ((unsigned long long)__builtin_bitreverse32(eh) << 32) | __builtin_bitreverse32(el);
+        if (partial && hbrow < WN - 1) {
+            const unsigned long long in_rows = (2ull << hbrow) - 1;         // rows 0..hbrow
+            free_w &= in_rows;
+            free_e &= in_rows;
+        }
+    }
     visit_result out;
     out.flat_bits = out.zmax_bits = FLAT_NONE;
 #ifdef HDEM_VISIT_PROF
@@ -992,37 +1040,61 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * FT, x0 = tx * FT, x = x0 + lane, xc = min(x, W - 1);
     float z[WN], w[WN];
+    // Z and W through buffer resources based at the window's first row: one literal multiple of
+    // the row pitch per row for both, no 64-bit address arithmetic.  Z's ends behind the
+    // raster's last row (window row hbrow; rows past it read 0, and nothing looks at them), W's
+    // before it: a store to a row that is not tile interior falls off the end and is dropped.
+    const int hbrow = H - 1 - y0;
+    const unsigned pitch = (unsigned)W * (unsigned)sizeof(float), col = (unsigned)xc * (unsigned)sizeof(float);
+    const size_t zbytes = (size_t)min(hbrow + 1, WN) * pitch, dbytes = (size_t)min(hbrow, WN) * pitch;
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(zg) + (size_t)y0 * W, 0, (int)(unsigned)zbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(
+        wg + (size_t)y0 * W, 0, (int)(unsigned)dbytes, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < WN; ++r) z[r] = zg[(size_t)min(y0 + r, H - 1) * W + xc];
-    unsigned long long nan_any = 0;
+    for (int r = 0; r < WN; ++r)
+        z[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            zrsrc, col, (unsigned)r * pitch, 0));
+    // any nodata in the window?  A sum is NaN as soon as one term is (one vector add per row,
+    // no scalar work; +inf next to -inf would say yes as well and only costs the slower path)
+    float zsum = 0.0f;
 #pragma unroll
-    for (int r = 0; r < WN; ++r) or_changed(nan_any, z[r], z[r]);      // (NaN != NaN)
+    for (int r = 0; r < WN; ++r) zsum += z[r];
+    const bool nan_any = __ballot(zsum != zsum) != 0;
     // last interior row / column of the window (62, less on the raster's last tiles)
     const int lr = min(FT, H - 2 - y0), lc = min(FT, W - 2 - x0);
     const bool lane_in = lane >= 1 && lane <= lc;
+    // (per lane: the last row that is tile interior in this lane, 0 = none -- what depends on
+    // the row is one vector compare against it, not scalar code per row)
+    const int row_in = lane_in ? lr : 0;
     bool outlet = false;
 #pragma unroll
     for (int r = 0; r < WN; ++r) w[r] = HDEM_INF;
     if (nan_any) {
-        // pinned cells of the fill -- nodata's 8 neighbours -- are the sources of this tile
-        unsigned long long a = __ballot(z[0] != z[0]), b = __ballot(z[1] != z[1]), pins = 0;
+        // pinned cells of the fill -- nodata's 8 neighbours -- are the sources of this tile.
+        // All in vector registers (flags 1.0 / 0.0, three rolling rows as in check_rows): with
+        // lane masks the compiler computed 64 ballots ahead of the branch and spilled them --
+        // 400 instructions on every tile for a path that few tiles take.
+        auto near_row = [&](float v) {
+            const float n = v != v ? 1.0f : 0.0f;
+            return fmaxf(fmaxf(n, lane_prev(n)), lane_next(n));
+        };
+        float h_prev = near_row(z[0]), h_cur = near_row(z[1]), any = 0.0f;
 #pragma unroll
         for (int r = 1; r <= FT; ++r) {
-            const unsigned long long c = __ballot(z[r + 1] != z[r + 1]);
-            unsigned long long m = a | b | c;
-            m |= (m << 1) | (m >> 1);
-            const bool src = lane_in && r <= lr && ((m >> lane) & 1ull) && z[r] == z[r];
+            const float h_next = near_row(z[r + 1]);
+            const bool src = r <= row_in && fmaxf(fmaxf(h_prev, h_cur), h_next) > 0.0f && z[r] == z[r];
             w[r] = src ? z[r] : HDEM_INF;
-            pins |= __ballot(src);
-            a = b;
-            b = c;
+            any = src ? 1.0f : any;
+            h_prev = h_cur;
+            h_cur = h_next;
         }
-        outlet = pins != 0;
+        outlet = __ballot(any != 0.0f) != 0;
     }
     // everything outside the tile interior, and nodata, is a wall (fminf drops the NaN)
+    z[0] = z[WN - 1] = HDEM_INF;
 #pragma unroll
-    for (int r = 0; r < WN; ++r)
-        z[r] = (lane_in && r >= 1 && r <= lr) ? fminf(z[r], HDEM_INF) : HDEM_INF;
+    for (int r = 1; r <= FT; ++r) z[r] = r <= row_in ? fminf(z[r], HDEM_INF) : HDEM_INF;
     float hz = HDEM_INF;
     if (!outlet) {
         float m = HDEM_INF;
@@ -1074,10 +1146,12 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
     e[3 * WN + lane] = col_e;
     if (lane == 0) node[t] = outlet ? __builtin_nanf("") : hz;
     if (lane_in) {
+        // (rows past the tile interior: beyond the resource's end, dropped)
 #pragma unroll
         for (int r = 1; r <= FT; ++r)
-            if (r <= lr)
-                wg[(size_t)(y0 + r) * W + x] = z[r] == HDEM_INF ? __builtin_nanf("") : w[r];
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned, z[r] == HDEM_INF ? __builtin_nanf("") : w[r]), drsrc,
+                col, (unsigned)r * pitch, 0);
     }
     }
 }
