@@ -195,10 +195,11 @@ def test_partition_hub_start_bounds_the_fill(built, world, rows, cols, holes):
     assert min(g[1] for g in got) > 0.3             # and tight: a third of the cells exact
 
 
-@pytest.mark.parametrize("world,rows,cols,holes,hub", [(4, 640, 1500, False, True),
-                                                       (3, 500, 900, True, False)])
+@pytest.mark.parametrize("world,rows,cols,holes,hub,eps", [(4, 640, 1500, False, True, 0.0),
+                                                           (3, 500, 900, True, False, 0.0),
+                                                           (3, 400, 700, True, True, 1e-3)])
 def test_partition_deferred_loop_matches_the_waiting_one(built, monkeypatch, world, rows, cols,
-                                                         holes, hub):
+                                                         holes, hub, eps):
     """The exchange loop that keeps its decisions on the device (HDEM_FILL_DEFER: seam words,
     solves enqueued without a host wait, vote looked at behind them) against the loop that
     reads every vote back first: same bits as the C oracle from both, on every rank, and the
@@ -209,7 +210,7 @@ def test_partition_deferred_loop_matches_the_waiting_one(built, monkeypatch, wor
     z = oracle.synth_dem(h, cols, variant="rough")
     if holes:
         z[rows - 9:rows + 12, 200:260] = np.nan
-    want = c_oracle.sinkfill_pflood(z)
+    want = c_oracle.sinkfill_pflood(z, eps)
     ghost = P.ghost_rows(world, h)
 
     def run(defer):
@@ -219,8 +220,8 @@ def test_partition_deferred_loop_matches_the_waiting_one(built, monkeypatch, wor
             g0, g1, _, _ = P.local_range(rank, world, h, ghost)
             zt = torch.from_numpy(z[g0:g1]).cuda()
             solver = P.HipLocalSolver(0, turn=comm.gpu_turn)
-            w, info = P.sinkfill_distributed(zt, rank, world, solver, ghost=ghost, comm=comm,
-                                             hub=hub, coarse_block=0)
+            w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps, ghost=ghost,
+                                             comm=comm, hub=hub, coarse_block=0)
             out = w.cpu().numpy()
             solver.ctx.close()
             return out, info, (g0, g1)
