@@ -664,7 +664,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     # ghost-changed words, a no-op when they are clear and nothing is queued -- and the vote is
     # looked at while it runs; a vote of "all at rest" means that solve found nothing to do.
     defer = world > 1 and w.is_cuda and getattr(solver, "can_defer", False) and \
-        os.environ.get("HDEM_PARTITION_DEFER", "1") != "0"
+        os.environ.get("HDEM_PARTITION_DEFER", "1") != "0" and \
+        "HDEM_FILL_SYNC" not in os.environ             # (a deferred call is an asynchronous launch)
     tally["deferred"] = 0
     while world > 1:
         if defer:
