@@ -369,18 +369,30 @@ __device__ __forceinline__ double wave_scan_f64(double p)
 // are read eight rows at a time.
 constexpr int H4T = 128, H4W = 4 * H4T;
 
-template <int RT, int r>
-__global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__restrict__ q, int h, int w,
-                                                             float factor, int seg,
-                                                             float *__restrict__ q_out,
-                                                             uint8_t *found, uint8_t *total,
-                                                             uint8_t *occ_mark,
-                                                             const uint8_t *__restrict__ occ_skip,
-                                                             int occ_w, int reach)
+// FULL: every column of the block lies inside the quadrant (all block columns but the first and
+// the last one or two): every lane loads 16 bytes from a clamped row WITHOUT a condition and a
+// row that does not exist is masked off afterwards.  With the loads under per-lane and per-row
+// conditions (the general form) the compiler cannot count what is in flight and waits for every
+// row load before it issues the next -- five round trips to L2 per row, which is what the "2.6 us
+// per row" of the note at the launch was made of.
+struct hollow_lds {
+    double pre[2][H4W + 1], sml[2][H4W + 1];   // inclusive prefixes inside each wave; [0] = 0
+    double wtot[2][2], wsml[2][2];             // the waves' totals
+};
+
+template <int RT, int r, bool FULL>
+__device__ __forceinline__ void hollow_detect4_body(hollow_lds &L, const float *__restrict__ q, int h,
+                                                    int w, float factor, int seg,
+                                                    float *__restrict__ q_out, uint8_t *found,
+                                                    uint8_t *total, uint8_t *occ_mark,
+                                                    const uint8_t *__restrict__ occ_skip, int occ_w,
+                                                    int reach)
 {
     const int R = RT ? RT : reach;
-    __shared__ double pre[2][H4W + 1], sml[2][H4W + 1];   // inclusive prefixes inside each wave; [0] = 0
-    __shared__ double wtot[2][2], wsml[2][2];             // the waves' totals
+    auto &pre = L.pre;
+    auto &sml = L.sml;
+    auto &wtot = L.wtot;
+    auto &wsml = L.wsml;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int outw = H4W - 2 * R;
     const int c_first = (int)blockIdx.x * outw - R, c0 = c_first + 4 * tid;
@@ -401,6 +413,13 @@ __global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__rest
     for (int k = 0; k < 4; ++k) live[k] = c0 + k >= 0 && c0 + k < w;
     // one row of my four columns (0 where the column or the row does not exist)
     auto load4 = [&](int y, bool want) -> hdem_f4 {
+        if (FULL) {
+            const unsigned keep = (want && y >= 0 && y < h) ? 0xffffffffu : 0u;     // uniform
+            hdem_f4 v = hdem_ld4u(q + (size_t)min(max(y, 0), h - 1) * w + c0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(__float_as_uint(v[k]) & keep);
+            return v;
+        }
         hdem_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!want || y < 0 || y >= h) return v;
         const float *row = q + (size_t)y * w;
@@ -445,7 +464,10 @@ __global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__rest
     }
     // (Issuing the next rows' loads before working on the current ones -- software pipelining
     // at 180 registers and two waves per SIMD -- is slower than this form at three: 0.37
-    // against 0.28 ms per launch.)
+    // against 0.28 ms per launch.  So are four rows per loop body, 0.27 against 0.26, and two
+    // rows' scans ahead of ONE barrier with four prefix buffers, 0.27: 32 KB of LDS per block
+    // leave two waves per SIMD.  What remains is float64 arithmetic at half rate: ~40 operations
+    // per cell are 0.15 ms of the 0.26.)
     constexpr int UN = 2;
     for (int yb = y0; yb < y1; yb += UN) {
         hdem_f4 in_b[UN], out_b[UN], in_s[UN], out_s[UN], cell[UN];
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__rest
             out_b[u] = load4(y - R, y < h);
             in_s[u] = load4(y + r + 1, true);
             out_s[u] = load4(y - r, y < h);
-            cell[u] = load4(y, any_out && y < y1);
+            cell[u] = load4(y, (FULL || any_out) && y < y1);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -534,6 +556,28 @@ __global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__rest
             }
         }
     }
+}
+
+// (one launch, both forms: a block's rows are a serial chain, and three launches -- first block
+// column, the full ones, the last -- cost three chains: 0.38 instead of 0.28 ms per pass)
+template <int RT, int r>
+__global__ __launch_bounds__(H4T) void hollow_detect4_kernel(const float *__restrict__ q, int h, int w,
+                                                             float factor, int seg,
+                                                             float *__restrict__ q_out,
+                                                             uint8_t *found, uint8_t *total,
+                                                             uint8_t *occ_mark,
+                                                             const uint8_t *__restrict__ occ_skip,
+                                                             int occ_w, int reach)
+{
+    __shared__ hollow_lds L;
+    const int R = RT ? RT : reach;
+    const int c_first = (int)blockIdx.x * (H4W - 2 * R) - R;
+    if (c_first >= 0 && c_first + H4W <= w)
+        hollow_detect4_body<RT, r, true>(L, q, h, w, factor, seg, q_out, found, total, occ_mark,
+                                         occ_skip, occ_w, reach);
+    else
+        hollow_detect4_body<RT, r, false>(L, q, h, w, factor, seg, q_out, found, total, occ_mark,
+                                          occ_skip, occ_w, reach);
 }
 
 // The detection masks are sparse (a handful of spectral peaks among 10^7..10^8 cells), so
