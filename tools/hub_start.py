@@ -54,6 +54,9 @@ for iters in iters_list:
     cr = np.empty((2 * ty + 1, 2 * tx + 1), dtype=np.float32)
     L.hub_edges(P(z), P(d), H, W, hub.ctypes.data_as(ip), P(cr))
     lev = np.ascontiguousarray(c_oracle.sinkfill_pflood(cr)[1::2, 1::2])
+    if os.environ.get("HUB_EXACT_LEVELS"):
+        # what a graph with exact hub levels would be worth: the oracle's fill at every hub
+        lev = np.ascontiguousarray(want.ravel()[hub].reshape(lev.shape).astype(np.float32))
     u = np.empty_like(z)
     L.hub_start(P(z), P(d), H, W, P(lev), P(u))
     bad = int((u < want).sum())
