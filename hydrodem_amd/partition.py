@@ -419,10 +419,9 @@ class _Seam:
         # busy, top, bottom (+ deferred loop: any of the three, the word that is voted on)
         self.word = torch.zeros(4, dtype=torch.int32, device=w.device)
         # deferred loop: the vote's copy on the host and the event that says it has arrived
-        self.vote_host = self.event = None
-        if w.is_cuda:
-            self.vote_host = torch.zeros(1, dtype=torch.int32, device="cpu", pin_memory=True)
-            self.event = torch.cuda.Event()
+        # (host tensors -- the CPU tests' solver -- need neither pinning nor an event)
+        self.vote_host = torch.zeros(1, dtype=torch.int32, device="cpu", pin_memory=w.is_cuda)
+        self.event = torch.cuda.Event() if w.is_cuda else None
 
 
 def _exchange_and_vote(comm, torch, w, top, bottom, pending, seam, ghost=1):
@@ -460,7 +459,8 @@ def _exchange_and_vote_deferred(comm, solver, w, top, bottom, pending, seam, gho
     solver.seam_apply(w, seam.recv_top, seam.recv_bot, pending, seam.word)
     busy = comm.all_reduce_max(seam.word[3:])
     seam.vote_host.copy_(busy, non_blocking=True)
-    seam.event.record()
+    if seam.event is not None:
+        seam.event.record()
 
 
 def coarse_start(z_local, comm, solver, block=COARSE_BLOCK, ghost=1):
@@ -663,7 +663,7 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
     # correcting solve behind it.  The solve is enqueued at once -- seeded on the device from the
     # ghost-changed words, a no-op when they are clear and nothing is queued -- and the vote is
     # looked at while it runs; a vote of "all at rest" means that solve found nothing to do.
-    defer = world > 1 and w.is_cuda and getattr(solver, "can_defer", False) and \
+    defer = world > 1 and getattr(solver, "can_defer", False) and \
         os.environ.get("HDEM_PARTITION_DEFER", "1") != "0" and \
         "HDEM_FILL_SYNC" not in os.environ             # (a deferred call is an asynchronous launch)
     tally["deferred"] = 0
@@ -676,7 +676,8 @@ def sinkfill_distributed(z_local, rank, world, solver, eps=0.0, w_out=None,
             solver.fill_deferred(z_local, w, eps, act, seam.word)
             tally["deferred"] += 1
             pending = -1                               # (on the device: seam.word[0])
-            seam.event.synchronize()
+            if seam.event is not None:
+                seam.event.synchronize()
             any_busy, ch_top, ch_bot = bool(seam.vote_host[0]), False, False
         else:
             any_busy, ch_top, ch_bot = _exchange_and_vote(comm, torch, w, top, bottom, pending,

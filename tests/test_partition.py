@@ -86,13 +86,49 @@ class NumpyLocalSolver:
         return torch.from_numpy(pad.reshape(ch, block, cw, block).max(axis=(1, 3)))
 
 
+class DeferringNumpySolver(NumpyLocalSolver):
+    """The same stand-in with the two calls of the deferred exchange loop
+    (``HipLocalSolver.seam_apply`` / ``fill_deferred``): seam words in a host tensor, the
+    correcting solve "enqueued" = run at once, nothing returned."""
+
+    can_defer = True
+
+    def __init__(self, slice_sweeps=3):
+        super().__init__(slice_sweeps)
+        self.deferred_calls = self.deferred_idle = 0
+
+    def seam_apply(self, w, recv_top, recv_bot, pending, words):
+        wn, k = w.numpy(), words.numpy()
+        if pending >= 0:
+            k[0] = int(pending > 0)
+        k[1] = k[2] = 0
+        for row, recv, slot in ((0, recv_top, 1), (wn.shape[0] - 1, recv_bot, 2)):
+            if recv is None:
+                continue
+            r = recv.numpy()
+            k[slot] = int(not np.array_equal(r.view(np.int32), wn[row].view(np.int32)))
+            wn[row] = r
+        k[3] = int(k[:3].max() > 0)
+
+    def fill_deferred(self, z, w, eps, flags, words):
+        assert flags & backend.FILL_WARM and flags & backend.FILL_RESUME
+        k = words.numpy()
+        self.deferred_calls += 1
+        if not k[:3].any():                            # (the library's launches leave at once)
+            self.deferred_idle += 1
+            return
+        _, _, pending = self.fill(z, w, eps, flags, sliced=True)
+        k[0] = int(pending > 0)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=4, ghost=1):
+def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=4, ghost=1,
+            deferring=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -105,10 +141,15 @@ def _worker(rank, world, port, H, W, eps, variant, nodata, outdir, coarse_block=
             full[H // 2 - 3:H // 2 + 3, 10:20] = np.nan        # straddles a seam for world=2
             z = full[g0:g1].copy()
         zt = torch.from_numpy(z)
-        solver = NumpyLocalSolver()
+        solver = DeferringNumpySolver() if deferring else NumpyLocalSolver()
         d = torch.empty(zt.shape, dtype=torch.uint8)
         w, info = P.sinkfill_distributed(zt, rank, world, solver, eps=eps,
                                          coarse_block=coarse_block, d8_out=d, ghost=ghost)
+        assert (info["deferred_solves"] > 0) == deferring
+        if deferring:
+            # one deferred solve per exchange, and the last of them -- behind the vote that
+            # said "all at rest" -- found nothing to do
+            assert solver.deferred_calls == info["exchanges"] and solver.deferred_idle >= 1
         assert torch.equal(d[P.owned_slice(rank, world, ghost)],
                            P.d8_distributed(w, solver)[P.owned_slice(rank, world, ghost)])
         own = P.owned_slice(rank, world, ghost)
@@ -161,10 +202,10 @@ def test_partitioned_fill_with_overlap_rows(tmp_path, world, H, W, eps, variant,
     (3, 75, 70, 0.0, "srtm", False, 8),
 ])
 def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata,
-                                                     coarse_block, ghost=1):
+                                                     coarse_block, ghost=1, deferring=False):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, H, W, eps, variant, nodata, str(tmp_path),
-                            coarse_block, ghost), nprocs=world, join=True)
+                            coarse_block, ghost, deferring), nprocs=world, join=True)
     z = oracle.synth_dem(H, W, variant=variant)
     if nodata:
         z[H // 2 - 3:H // 2 + 3, 10:20] = np.nan
@@ -177,6 +218,21 @@ def test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps,
     assert np.array_equal(np.nan_to_num(got_w, nan=-1), np.nan_to_num(want_w, nan=-1))
     assert np.array_equal(got_d, want_d)
     assert all(int(p["exchanges"]) >= 2 for p in parts)     # information did cross the seam
+
+
+@pytest.mark.parametrize("world,H,W,eps,variant,nodata,coarse_block,ghost", [
+    (2, 96, 80, 0.0, "rough", False, 4, 1),
+    (3, 100, 90, 0.0, "rough", True, 0, 1),       # +inf ghost rows: several rounds of corrections
+    (2, 64, 48, 1e-3, "rough", False, 4, 1),
+    (3, 130, 70, 0.0, "srtm", False, 4, 8),       # overlap rows
+])
+def test_partitioned_fill_with_the_deferred_exchange_loop(tmp_path, world, H, W, eps, variant,
+                                                          nodata, coarse_block, ghost):
+    """The exchange loop that does not come back to the host between an exchange and the solve
+    behind it (seam words, deferred solves, the vote looked at afterwards), over gloo between
+    real processes: a solver with the two extra calls takes it, and the result is the oracle's."""
+    test_partitioned_fill_and_d8_equal_unpartitioned(tmp_path, world, H, W, eps, variant, nodata,
+                                                     coarse_block, ghost, deferring=True)
 
 
 def _stencil_worker(rank, world, port, H, W, iters, outdir):
