@@ -470,6 +470,25 @@ __device__ __forceinline__ rowbits any5(rowbits m)
     return m | (m << 1) | (m >> 1) | (m << 2) | (m >> 2);
 }
 
+// lane i <- lane i -+ 1 across the wave (gfx9 wave_shr / wave_shl; the lane without a source
+// reads 0 -- tile columns 0..2 and 61..63, which are never outputs)
+__device__ __forceinline__ float tidy_prev(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float tidy_next(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+        0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+// max of two numbers that are not NaN, as ONE instruction (fmaxf brings a canonicalisation of
+// each operand with it)
+__device__ __forceinline__ float tidy_max(float a, float b)
+{
+    return __builtin_amdgcn_fmed3f(a, b, __builtin_inff());
+}
+
 __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict__ in, int h, int w,
                                                         float *__restrict__ out,
                                                         uint8_t *__restrict__ positive)
@@ -478,7 +497,9 @@ __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict_
     __shared__ float ti[FTH * FTW];
     __shared__ rowbits nz[FTH], eroded[FTH], expanded[FTH], nans[FTH];
     const int x0 = blockIdx.x * FTX - FREACH, y0 = blockIdx.y * FTY - FREACH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a scalar: the rows' reflections -- a modulo each -- are then scalar code
+    // instead of ~35 vector instructions per row and lane, which was half of this kernel)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gx = x0 + lane;
     {   // all loads of the thread in flight before the first ballot waits for one
         constexpr int ROWS = FTH / (NT / 64);
@@ -523,45 +544,44 @@ __global__ __launch_bounds__(NT) void tidy_fused_kernel(const float *__restrict_
         expanded[r] = x;
     }
     __syncthreads();
-    // product and row maxima, in place: a tile row belongs to one wave, whose LDS
-    // operations run in order, so its 7 reads are done before its write; a NaN is never
-    // "greater" and only survives at the centre, which nans[] remembers
+    // Product and row maxima.  The kernel is bound by its vector instructions (SQ counters,
+    // round 3: 511 M per launch at 16384^2 = the 0.87 ms it took), so the two running maxima are
+    // written for few of them: a NaN is never "greater" and only survives at the centre, which
+    // nans[] remembers -- it becomes -inf here and plain maxima do the rest;
+    //   rows: the 7-wide maximum as three doublings of wave shifts ([-1..1], [-2..2], [-3..3]:
+    //         6 maxima on registers instead of 7 clamped LDS reads and 7 compare-selects);
+    //   columns: m2[k] = max(x[k], x[k+1]), m4[k] = max(m2[k], m2[k+2]), m7[k] = max(m4[k],
+    //         m4[k+3]) over the 22 row maxima a lane needs for its 16 outputs: 3.5 maxima per
+    //         output instead of 14 operations.
     for (int ly = wave; ly < FTH; ly += NT / 64) {
         float *row = ti + ly * FTW;
         const float p = row[lane] * ((expanded[ly] >> lane) & 1 ? 1.0f : 0.0f);
-        row[lane] = p;
-        const rowbits isnan = __ballot(p != p);
+        const bool gone = p != p;
+        const rowbits isnan = __ballot(gone);
         if (lane == 0) nans[ly] = isnan;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float m = -__builtin_inff();
-#pragma unroll
-        for (int dx = -3; dx <= 3; ++dx) {
-            const float v = row[min(max(lane + dx, 0), FTW - 1)];
-            m = v > m ? v : m;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        row[lane] = m;
+        const float q = gone ? -__builtin_inff() : p;
+        const float a = tidy_max(tidy_max(q, tidy_prev(q)), tidy_next(q));
+        const float b = tidy_max(tidy_prev(a), tidy_next(a));
+        row[lane] = tidy_max(tidy_prev(b), tidy_next(b));
     }
     __syncthreads();
     if (lane < FREACH || lane >= FTW - FREACH || gx >= w) return;
-    // each wave takes FTY / 4 consecutive rows and keeps the 7 row maxima in registers
+    // each wave takes FTY / 4 consecutive rows
     constexpr int PER = FTY / (NT / 64);
     const int first = FREACH + wave * PER;
-    float win[7];
+    float x[PER + 6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) win[k + 1] = ti[(first - 3 + k) * FTW + lane];
+    for (int k = 0; k < PER + 6; ++k) x[k] = ti[(first - 3 + k) * FTW + lane];
+#pragma unroll
+    for (int k = 0; k < PER + 5; ++k) x[k] = tidy_max(x[k], x[k + 1]);          // rows k .. k+1
+#pragma unroll
+    for (int k = 0; k < PER + 3; ++k) x[k] = tidy_max(x[k], x[k + 2]);          // rows k .. k+3
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int ly = first + k, gy = y0 + ly;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) win[j] = win[j + 1];
-        win[6] = ti[(ly + 3) * FTW + lane];
         if (gy >= h) break;
-        float m = (nans[ly] >> lane) & 1 ? __builtin_nanf("") : -__builtin_inff();
-#pragma unroll
-        for (int j = 0; j < 7; ++j) m = win[j] > m ? win[j] : m;
+        const float m7 = tidy_max(x[k], x[k + 3]);                             // rows k .. k+6
+        const float m = (nans[ly] >> lane) & 1 ? __builtin_nanf("") : m7;
         out[(size_t)gy * w + gx] = m;
         if (positive) positive[(size_t)gy * w + gx] = m > 0.0f;
     }
