@@ -195,7 +195,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gr
     // instead of by every lane that reads it: 5 instead of 20 subtractions per lane-row)
     __shared__ __attribute__((aligned(16))) float raw[4][NSLOT][SW_COLS];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave index as a scalar: strip origin, row addresses and range tests are then scalar
+    // code instead of per-lane vector arithmetic)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strip = blockIdx.x * 4 + wave;
     if (strip >= nstrips) return;
     const int sy = strip / strips_x, sx = sx0 + strip - sy * strips_x;
