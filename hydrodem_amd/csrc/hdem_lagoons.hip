@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT) void majority_walk_kernel(const float *__restri
         dst[1] = (u4){packed[4], packed[5], packed[6], packed[7]};
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * RPW;
+    const int lx = threadIdx.x & 63, r0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * RPW;
     const int x = x0 + lx;
     unsigned sm[RPW + WS - 1];
 #pragma unroll
