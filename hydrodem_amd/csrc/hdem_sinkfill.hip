@@ -1036,7 +1036,16 @@ __global__ __launch_bounds__(NT, 2) void hub_dist_kernel(const float *__restrict
 {
     __shared__ float T[WN * TS];
     const int lane = threadIdx.x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by index, each XCD with an
+    // L2 of its own.  Workgroup b takes tile (b % 8) * per + b / 8, so every XCD walks one
+    // contiguous eighth of the tiles and the tiles in flight on it are neighbours in a tile row:
+    // the 128-byte lines that two adjacent windows share (a window row is 256 bytes at a
+    // multiple of 248: three lines, the outer two shared) are fetched once per XCD, and the two
+    // halves of a line that two tiles write meet in one L2.
+    const int per = (ntiles + 7) / 8;
+    for (int b = blockIdx.x; b < 8 * per; b += gridDim.x) {
+    const int t = (b & 7) * per + (b >> 3);
+    if (t >= ntiles) continue;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     const int y0 = ty * FT, x0 = tx * FT, x = x0 + lane, xc = min(x, W - 1);
     float z[WN], w[WN];
@@ -1711,7 +1720,7 @@ void hub_launch_dist(hdem_ctx *ctx, const float *z, float *w, int H, int W, cons
     // one workgroup per tile: a resident grid of 8 per CU walking the tiles was measured
     // at 0.77 against 0.64 ms (HDEM_HUB_WGS: that grid, per CU)
     const int grid = getenv("HDEM_HUB_WGS") ? std::min(ntiles, ctx->num_cus * atoi(getenv("HDEM_HUB_WGS")))
-                                            : ntiles;
+                                            : (ntiles + 7) / 8 * 8;     // (whole rounds of the 8 XCDs)
     hipStream_t st = ctx->stream;
     if (iters >= 4)
         hipLaunchKernelGGL(hub_dist_kernel<4>, dim3(grid), dim3(NT), 0, st, z, w, H, W, hb.tiles_x,
