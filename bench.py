@@ -630,7 +630,7 @@ def main():
                             ms_per_step=kh["ms"] / a.steps,
                             note="hub start: per tile the minimax path cost of every cell to "
                                  "the tile's hub (Z in, d out) + the crossings between hubs; "
-                                 "two rounds of directional scans per tile, instruction-bound"),
+                                 "three rounds of directional scans per tile; waits on its loads and stores (its time does not depend on the number of rounds), tiles in XCD-aware order"),
                         "start_raster_solve": {
                             "blockmax_avg_launch_ms": kb["ms"] / max(kb["launches"], 1),
                             "fill_async_kernel<false, 1>_avg_launch_ms":
