@@ -50,6 +50,43 @@ static void tile_box(int H, int W, int ty, int tx, int *y0, int *y1, int *x0, in
 // d: H x W (only interior cells written); hub: per tile flat index of the hub cell.
 // nhub hubs per tile side (1: one hub per tile; 2: four sub-blocks, each relaxed inside its own
 // sub-block -- d then refers to the sub-block's hub).
+static int g_margin = 0;
+void hub_set_margin(int m) { g_margin = m; }
+
+// exact minimax distances to the tile's hub over the tile grown by g_margin cells (paths may
+// leave the tile by that much); written for the tile's own cells only
+static void dist_margin(const float *z, int H, int W, int y0, int y1, int x0, int x1, int hy, int hx, float *d)
+{
+    const int m = g_margin;
+    const int Y0 = y0 - m < 1 ? 1 : y0 - m, Y1 = y1 + m > H - 2 ? H - 2 : y1 + m;
+    const int X0 = x0 - m < 1 ? 1 : x0 - m, X1 = x1 + m > W - 2 ? W - 2 : x1 + m;
+    const int hh = Y1 - Y0 + 1, ww = X1 - X0 + 1;
+    float *w = (float *)malloc(sizeof(float) * hh * ww);
+    item *heap = (item *)malloc(sizeof(item) * 16 * hh * ww);
+    for (int i = 0; i < hh * ww; ++i) w[i] = INFINITY;
+    int n = 0;
+    w[(hy - Y0) * ww + hx - X0] = z[(size_t)hy * W + hx];
+    push(heap, &n, w[(hy - Y0) * ww + hx - X0], (hy - Y0) * ww + hx - X0);
+    while (n) {
+        item it = pop(heap, &n);
+        const int r = it.i / ww, c = it.i % ww;
+        if (it.k > w[it.i]) continue;
+        for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
+            const int rr = r + dr, cc = c + dc;
+            if (rr < 0 || rr >= hh || cc < 0 || cc >= ww) continue;
+            const float zz = z[(size_t)(Y0 + rr) * W + X0 + cc];
+            if (!(zz == zz)) continue;
+            const float nd = it.k > zz ? it.k : zz;
+            if (nd < w[rr * ww + cc]) { w[rr * ww + cc] = nd; push(heap, &n, nd, rr * ww + cc); }
+        }
+    }
+    for (int y = y0; y <= y1; ++y) for (int x = x0; x <= x1; ++x) {
+        const float v = w[(y - Y0) * ww + x - X0];
+        d[(size_t)y * W + x] = v == INFINITY ? BIG : v;
+    }
+    free(w); free(heap);
+}
+
 void hub_dist(const float *z, int H, int W, int iters, float *d, int64_t *hub)
 {
     const int tiles_y = (H - 2 + FT - 1) / FT, tiles_x = (W - 2 + FT - 1) / FT;
@@ -75,6 +112,10 @@ void hub_dist(const float *z, int H, int W, int iters, float *d, int64_t *hub)
                 }
             hub[t] = (int64_t)(y0 + hy) * W + x0 + hx;
             w[hy + 1][hx + 1] = hz;
+            if (g_margin > 0) {
+                dist_margin(z, H, W, y0, y1, x0, x1, y0 + hy, x0 + hx, d);
+                continue;
+            }
             if (iters == 0) {
                 int n = 0;
                 push(heap, &n, hz, (hy + 1) * (FT + 2) + hx + 1);

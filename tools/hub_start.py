@@ -47,6 +47,9 @@ if use_gpu:
     print(f"fill WARM from the answer: {1e3*(time.time()-t):.2f} ms, visits {st['tile_visits']}", flush=True)
     ud.free()
 
+if os.environ.get("HUB_MARGIN"):
+    # paths to the hub may leave the tile by this many cells (exact distances over the grown tile)
+    L.hub_set_margin(int(os.environ["HUB_MARGIN"]))
 for iters in iters_list:
     t0 = time.time()
     d = np.empty_like(z); hub = np.empty(ty * tx, dtype=np.int64)
