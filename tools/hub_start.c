@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef FT
 #define FT 62
+#endif
 #define BIG 3.0e38f
 
 typedef struct { float k; int i; } item;

@@ -15,7 +15,8 @@ import hdem_synth
 from oracle import c_oracle
 
 so = os.path.join(HERE, "_hub_start.so")
-subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", so,
+T = int(os.environ.get("HUB_T", "62"))                # edge of the hub tiles (the fill's own stay 62)
+subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", f"-DFT={T}", "-o", so,
                        os.path.join(HERE, "hub_start.c"), "-lm"])
 L = ctypes.CDLL(so)
 fp = ctypes.POINTER(ctypes.c_float); ip = ctypes.POINTER(ctypes.c_int64)
@@ -24,7 +25,6 @@ P = lambda a: a.ctypes.data_as(fp)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters_list = [int(a) for a in sys.argv[2:]] or [0]
 variant = os.environ.get("HUB_VARIANT", "rough")
-T = 62
 z = hdem_synth.synth_dem(n, n, variant=variant)
 H = W = n
 ty = tx = (n - 2 + T - 1) // T
